@@ -1,0 +1,1148 @@
+// C ABI (include/nvllm_amd.h) over the gfx950 kernels: context, model (weights in MFMA tile layout),
+// native KV block pool, the ModelRunner::run-shaped step, and the fine-seam ops.
+// Host C++ compiled with hipcc.  No CPU compute fallback exists anywhere in this file: every
+// arithmetic result comes from a kernel in kernels.hip.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/nvllm_amd.h"
+#include "kernels.h"
+#include "synth_device.h"
+
+using namespace nvllm;
+
+// ---------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------
+struct nvllm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int tp_rank = 0, tp_size = 1;
+    ncclComm_t comm = nullptr;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(nvllm_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(ctx, NVLLM_EHIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+#define NCCLCHK(ctx, expr)                                                                               \
+    do {                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess) return fail(ctx, NVLLM_ERCCL, "%s -> %s", #expr, ncclGetErrorString(r_)); \
+    } while (0)
+
+extern "C" const char* nvllm_last_error(const nvllm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int nvllm_rccl_unique_id(void* out_id) {
+    static_assert(sizeof(ncclUniqueId) <= NVLLM_RCCL_ID_BYTES, "id size");
+    if (!out_id) return fail(nullptr, NVLLM_EINVAL, "out_id is NULL");
+    ncclUniqueId id;
+    NCCLCHK(nullptr, ncclGetUniqueId(&id));
+    memset(out_id, 0, NVLLM_RCCL_ID_BYTES);
+    memcpy(out_id, &id, sizeof id);
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_ctx_create(int device_ordinal, int tp_rank, int tp_size, const void* rccl_id, nvllm_ctx** out) {
+    if (!out) return fail(nullptr, NVLLM_EINVAL, "out is NULL");
+    if (tp_size < 1) return fail(nullptr, NVLLM_EINVAL, "tp_size must be >= 1");
+    if (tp_rank < 0 || tp_rank >= tp_size) tp_rank = 0;  // src/tp.rs:24-29
+    int ndev = 0;
+    HIPCHK(nullptr, hipGetDeviceCount(&ndev));
+    if (device_ordinal < 0 || device_ordinal >= ndev)
+        return fail(nullptr, NVLLM_EINVAL, "device %d not present (%d devices)", device_ordinal, ndev);
+    HIPCHK(nullptr, hipSetDevice(device_ordinal));
+    nvllm_ctx* c = new nvllm_ctx();
+    c->device = device_ordinal;
+    c->tp_rank = tp_rank;
+    c->tp_size = tp_size;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(nullptr, NVLLM_EHIP, "stream/event create -> %s", hipGetErrorString(e));
+    }
+    if (tp_size > 1) {
+        if (!rccl_id) { delete c; return fail(nullptr, NVLLM_EINVAL, "tp_size>1 needs an RCCL unique id"); }
+        ncclUniqueId id;
+        memcpy(&id, rccl_id, sizeof id);
+        ncclResult_t r = ncclCommInitRank(&c->comm, tp_size, id, tp_rank);
+        if (r != ncclSuccess) {
+            delete c;
+            return fail(nullptr, NVLLM_ERCCL, "ncclCommInitRank -> %s", ncclGetErrorString(r));
+        }
+    }
+    *out = c;
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_ctx_destroy(nvllm_ctx* c) {
+    if (!c) return NVLLM_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm) ncclCommDestroy(c->comm);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return NVLLM_OK;
+}
+extern "C" int nvllm_ctx_synchronize(nvllm_ctx* c) {
+    if (!c) return NVLLM_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NVLLM_OK;
+}
+extern "C" void* nvllm_ctx_stream(nvllm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int nvllm_ctx_tp_rank(const nvllm_ctx* c) { return c ? c->tp_rank : 0; }
+extern "C" int nvllm_ctx_tp_size(const nvllm_ctx* c) { return c ? c->tp_size : 1; }
+extern "C" int nvllm_timer_start(nvllm_ctx* c) {
+    if (!c) return NVLLM_EINVAL;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    return NVLLM_OK;
+}
+extern "C" int nvllm_timer_stop(nvllm_ctx* c, float* ms) {
+    if (!c || !ms) return NVLLM_EINVAL;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return NVLLM_OK;
+}
+
+// device memory helpers -------------------------------------------------------------------------------
+extern "C" int nvllm_dev_alloc(nvllm_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return NVLLM_EINVAL;
+    HIPCHK(c, hipMalloc(out, bytes ? bytes : 16));
+    return NVLLM_OK;
+}
+extern "C" int nvllm_dev_free(nvllm_ctx* c, void* p) {
+    if (!c) return NVLLM_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(p));
+    return NVLLM_OK;
+}
+extern "C" int nvllm_dev_upload(nvllm_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) return NVLLM_EINVAL;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NVLLM_OK;
+}
+extern "C" int nvllm_dev_download(nvllm_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) return NVLLM_EINVAL;
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NVLLM_OK;
+}
+
+template <typename T>
+static int dmalloc(nvllm_ctx* c, T** p, size_t count) {
+    HIPCHK(c, hipMalloc((void**)p, std::max<size_t>(count * sizeof(T), 16)));
+    return NVLLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------------------------------
+struct LayerW {
+    PackedW qkv, o, gu, down;
+    float *ln1 = nullptr, *ln2 = nullptr, *qn = nullptr, *kn = nullptr;
+};
+
+struct SeqState {
+    int slot = -1;
+    int cached = 0;  // tokens whose K/V are in the cache
+    std::vector<int> blocks;
+};
+
+struct nvllm_model {
+    nvllm_ctx* ctx = nullptr;
+    nvllm_qwen3_config cfg{};
+    int H = 0, hd = 0, L = 0, nh_l = 0, kv_l = 0, I_l = 0, V_l = 0, gqa = 1;
+    bf16_bits* embed = nullptr;  // [V][H] row-major bf16 (gather table, replicated)
+    PackedW lm_head;             // [V_l][H]
+    float* norm = nullptr;
+    std::vector<LayerW> layers;
+    std::unordered_map<std::string, bool> loaded;
+    bool finalized = false;
+    float *cosv = nullptr, *sinv = nullptr;
+    int rope_len = 0;
+
+    // KV pool
+    int num_blocks = 0, max_seqs = 0, max_blocks = 0, max_rows = 0;
+    std::vector<f16_bits*> kcache, vcache;
+    std::vector<int> free_blocks, free_slots;
+    std::unordered_map<int64_t, SeqState> seqs;
+    int* d_block_tables = nullptr;
+    std::vector<int> h_block_tables;
+
+    // step buffers
+    uint32_t* d_ids = nullptr;
+    int *d_pos = nullptr, *d_slot = nullptr, *d_tile_row0 = nullptr, *d_tile_nrows = nullptr, *d_tile_slot = nullptr,
+        *d_last_rows = nullptr;
+    float *resid = nullptr, *slabs = nullptr, *qbuf = nullptr, *logits = nullptr, *d_maxval = nullptr, *red = nullptr;
+    bf16_bits *xh = nullptr, *xl = nullptr;
+    uint32_t* d_next = nullptr;
+    size_t slab_floats = 0;
+    void* h_stage = nullptr;  // pinned
+    size_t h_stage_bytes = 0;
+    float *tap_h = nullptr, *tap_res = nullptr;
+    bool taps = false;
+    int tap_rows = 0;
+
+    // last step (for nvllm_decode_next / byte accounting)
+    std::vector<int64_t> last_ids;
+    std::vector<int> last_lens;
+    int64_t last_bytes = 0;
+    bool decode_resident = false;  // device metadata describes a pure-decode batch == last_ids
+};
+
+static int model_fail(nvllm_model* m, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    m->ctx->err = buf;
+    return code;
+}
+
+static const char* kLayerTensors[] = {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                                      "self_attn.o_proj.weight", "mlp.gate_proj.weight",    "mlp.up_proj.weight",
+                                      "mlp.down_proj.weight",    "input_layernorm.weight",  "post_attention_layernorm.weight",
+                                      "self_attn.q_norm.weight", "self_attn.k_norm.weight"};
+
+extern "C" int nvllm_model_create(nvllm_ctx* ctx, const nvllm_qwen3_config* cfg, nvllm_model** out) {
+    if (!ctx || !cfg || !out) return fail(ctx, NVLLM_EINVAL, "NULL argument");
+    const int tp = ctx->tp_size;
+    const nvllm_qwen3_config& c = *cfg;
+    if (c.vocab_size <= 0 || c.hidden_size <= 0 || c.num_hidden_layers <= 0 || c.num_attention_heads <= 0 ||
+        c.num_key_value_heads <= 0 || c.intermediate_size <= 0 || c.head_dim <= 0)
+        return fail(ctx, NVLLM_EINVAL, "config has non-positive sizes");
+    if (c.head_dim != 64 && c.head_dim != 128) return fail(ctx, NVLLM_EINVAL, "head_dim %d unsupported (64 or 128)", c.head_dim);
+    if (c.num_attention_heads % c.num_key_value_heads) return fail(ctx, NVLLM_EINVAL, "num_heads %% num_kv_heads != 0");
+    if (c.num_attention_heads / c.num_key_value_heads > 16) return fail(ctx, NVLLM_EINVAL, "GQA group > 16 unsupported");
+    if (c.num_key_value_heads % tp || c.num_attention_heads % tp)
+        return fail(ctx, NVLLM_EINVAL, "heads (%d q / %d kv) not divisible by tp_size %d", c.num_attention_heads, c.num_key_value_heads, tp);
+    if (c.hidden_size % 32 || c.hidden_size > 8192) return fail(ctx, NVLLM_EINVAL, "hidden_size must be a multiple of 32 and <= 8192");
+    if (c.intermediate_size % (32 * tp)) return fail(ctx, NVLLM_EINVAL, "intermediate_size must be a multiple of 32*tp");
+    if (c.vocab_size % (16 * tp)) return fail(ctx, NVLLM_EINVAL, "vocab_size must be a multiple of 16*tp");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    nvllm_model* m = new nvllm_model();
+    m->ctx = ctx;
+    m->cfg = c;
+    m->H = c.hidden_size; m->hd = c.head_dim; m->L = c.num_hidden_layers;
+    m->nh_l = c.num_attention_heads / tp; m->kv_l = c.num_key_value_heads / tp;
+    m->I_l = c.intermediate_size / tp; m->V_l = c.vocab_size / tp;
+    m->gqa = c.num_attention_heads / c.num_key_value_heads;
+    const int H = m->H, hd = m->hd;
+    auto alloc_w = [&](PackedW& w, int N, int K) -> int {
+        w.N = N; w.K = K;
+        HIPCHK(ctx, hipMalloc((void**)&w.data, w.bytes()));
+        return NVLLM_OK;
+    };
+    int rc = dmalloc(ctx, &m->embed, (size_t)c.vocab_size * H);
+    if (!rc) rc = alloc_w(m->lm_head, m->V_l, H);
+    if (!rc) rc = dmalloc(ctx, &m->norm, H);
+    m->layers.resize(m->L);
+    for (int l = 0; l < m->L && !rc; ++l) {
+        LayerW& w = m->layers[l];
+        rc = alloc_w(w.qkv, (m->nh_l + 2 * m->kv_l) * hd, H);
+        if (!rc) rc = alloc_w(w.o, H, m->nh_l * hd);
+        if (!rc) rc = alloc_w(w.gu, 2 * m->I_l, H);
+        if (!rc) rc = alloc_w(w.down, H, m->I_l);
+        if (!rc) rc = dmalloc(ctx, &w.ln1, H);
+        if (!rc) rc = dmalloc(ctx, &w.ln2, H);
+        if (!rc) rc = dmalloc(ctx, &w.qn, hd);
+        if (!rc) rc = dmalloc(ctx, &w.kn, hd);
+    }
+    if (rc) { nvllm_model_destroy(m); return rc; }
+    *out = m;
+    return NVLLM_OK;
+}
+
+static void free_kv(nvllm_model* m) {
+    for (auto p : m->kcache) (void)hipFree(p);
+    for (auto p : m->vcache) (void)hipFree(p);
+    m->kcache.clear(); m->vcache.clear();
+    void* ptrs[] = {m->d_block_tables, m->d_ids, m->d_pos, m->d_slot, m->d_tile_row0, m->d_tile_nrows, m->d_tile_slot,
+                    m->d_last_rows, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->d_next,
+                    m->tap_h, m->tap_res, m->cosv, m->sinv};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    m->d_block_tables = nullptr; m->d_ids = nullptr; m->d_pos = m->d_slot = m->d_tile_row0 = m->d_tile_nrows = m->d_tile_slot = m->d_last_rows = nullptr;
+    m->resid = m->slabs = m->qbuf = m->logits = m->d_maxval = m->red = nullptr; m->xh = m->xl = nullptr; m->d_next = nullptr;
+    m->tap_h = m->tap_res = nullptr; m->cosv = m->sinv = nullptr;
+    if (m->h_stage) (void)hipHostFree(m->h_stage);
+    m->h_stage = nullptr;
+    m->num_blocks = 0;
+}
+
+extern "C" int nvllm_model_destroy(nvllm_model* m) {
+    if (!m) return NVLLM_OK;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    free_kv(m);
+    (void)hipFree(m->embed); (void)hipFree(m->lm_head.data); (void)hipFree(m->norm);
+    for (auto& w : m->layers) {
+        (void)hipFree(w.qkv.data); (void)hipFree(w.o.data); (void)hipFree(w.gu.data); (void)hipFree(w.down.data);
+        (void)hipFree(w.ln1); (void)hipFree(w.ln2); (void)hipFree(w.qn); (void)hipFree(w.kn);
+    }
+    delete m;
+    return NVLLM_OK;
+}
+
+// Where an HF tensor lands: a region (rows r0.., cols c0..) of the full tensor goes to rows
+// [dst_row0, dst_row0+rows) of a packed matrix / or to a plain f32 / bf16 row-major buffer.
+struct Target {
+    enum Kind { PACKED, F32VEC, BF16ROWS } kind = PACKED;
+    PackedW* w = nullptr;
+    float* f = nullptr;
+    bf16_bits* b = nullptr;
+    int64_t full_rows = 0, full_cols = 0;  // HF shape
+    int64_t r0 = 0, c0 = 0, rows = 0, cols = 0;  // shard region
+    int dst_row0 = 0;
+    int synth_kind = kSynthMatrix;
+};
+
+static bool resolve(nvllm_model* m, const char* name, Target& t) {
+    const nvllm_qwen3_config& c = m->cfg;
+    const int rank = m->ctx->tp_rank;
+    const int64_t H = m->H, hd = m->hd, nh = c.num_attention_heads, kv = c.num_key_value_heads, I = c.intermediate_size, V = c.vocab_size;
+    if (!strcmp(name, "model.embed_tokens.weight")) {
+        t.kind = Target::BF16ROWS; t.b = m->embed; t.full_rows = V; t.full_cols = H; t.rows = V; t.cols = H; return true;
+    }
+    if (!strcmp(name, "lm_head.weight")) {
+        t.w = &m->lm_head; t.full_rows = V; t.full_cols = H; t.r0 = (int64_t)rank * m->V_l; t.rows = m->V_l; t.cols = H; return true;
+    }
+    if (!strcmp(name, "model.norm.weight")) {
+        t.kind = Target::F32VEC; t.f = m->norm; t.full_rows = 1; t.full_cols = H; t.rows = 1; t.cols = H; t.synth_kind = kSynthNorm; return true;
+    }
+    int l = -1, off = 0;
+    if (sscanf(name, "model.layers.%d.%n", &l, &off) != 1 || l < 0 || l >= m->L || off == 0) return false;
+    const char* s = name + off;
+    LayerW& w = m->layers[l];
+    const int64_t qr = (int64_t)m->nh_l * hd, kr = (int64_t)m->kv_l * hd;
+    if (!strcmp(s, "self_attn.q_proj.weight")) { t.w = &w.qkv; t.full_rows = nh * hd; t.full_cols = H; t.r0 = rank * qr; t.rows = qr; t.cols = H; t.dst_row0 = 0; return true; }
+    if (!strcmp(s, "self_attn.k_proj.weight")) { t.w = &w.qkv; t.full_rows = kv * hd; t.full_cols = H; t.r0 = rank * kr; t.rows = kr; t.cols = H; t.dst_row0 = (int)qr; return true; }
+    if (!strcmp(s, "self_attn.v_proj.weight")) { t.w = &w.qkv; t.full_rows = kv * hd; t.full_cols = H; t.r0 = rank * kr; t.rows = kr; t.cols = H; t.dst_row0 = (int)(qr + kr); return true; }
+    if (!strcmp(s, "self_attn.o_proj.weight")) { t.w = &w.o; t.full_rows = H; t.full_cols = nh * hd; t.c0 = rank * qr; t.rows = H; t.cols = qr; return true; }
+    if (!strcmp(s, "mlp.gate_proj.weight")) { t.w = &w.gu; t.full_rows = I; t.full_cols = H; t.r0 = (int64_t)rank * m->I_l; t.rows = m->I_l; t.cols = H; t.dst_row0 = 0; return true; }
+    if (!strcmp(s, "mlp.up_proj.weight")) { t.w = &w.gu; t.full_rows = I; t.full_cols = H; t.r0 = (int64_t)rank * m->I_l; t.rows = m->I_l; t.cols = H; t.dst_row0 = m->I_l; return true; }
+    if (!strcmp(s, "mlp.down_proj.weight")) { t.w = &w.down; t.full_rows = H; t.full_cols = I; t.c0 = (int64_t)rank * m->I_l; t.rows = H; t.cols = m->I_l; return true; }
+    t.kind = Target::F32VEC; t.synth_kind = kSynthNorm; t.full_rows = 1; t.rows = 1;
+    if (!strcmp(s, "input_layernorm.weight")) { t.f = w.ln1; t.full_cols = t.cols = H; return true; }
+    if (!strcmp(s, "post_attention_layernorm.weight")) { t.f = w.ln2; t.full_cols = t.cols = H; return true; }
+    if (!strcmp(s, "self_attn.q_norm.weight")) { t.f = w.qn; t.full_cols = t.cols = hd; return true; }
+    if (!strcmp(s, "self_attn.k_norm.weight")) { t.f = w.kn; t.full_cols = t.cols = hd; return true; }
+    return false;
+}
+
+static inline uint16_t host_f32_to_bf16(float f) {  // round-to-nearest-even (exact for bf16-valued inputs)
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+extern "C" int nvllm_model_load_tensor(nvllm_model* m, const char* hf_name, const void* host_data, int dtype,
+                                       const int64_t* shape, int ndim) {
+    if (!m || !hf_name || !host_data || !shape) return fail(m ? m->ctx : nullptr, NVLLM_EINVAL, "NULL argument");
+    nvllm_ctx* ctx = m->ctx;
+    if (dtype != NVLLM_DTYPE_F32 && dtype != NVLLM_DTYPE_BF16) return fail(ctx, NVLLM_EINVAL, "dtype %d unsupported", dtype);
+    Target t;
+    if (!resolve(m, hf_name, t)) return fail(ctx, NVLLM_EINVAL, "unknown tensor name '%s'", hf_name);
+    int64_t rows = ndim == 2 ? shape[0] : 1, cols = ndim == 2 ? shape[1] : (ndim == 1 ? shape[0] : -1);
+    if (ndim == 2 && t.kind == Target::F32VEC && shape[0] == 1) { rows = 1; cols = shape[1]; }  // [1,H] norm weight (qwen3.rs:180)
+    if (cols != t.full_cols || rows != t.full_rows)
+        return fail(ctx, NVLLM_EINVAL, "tensor '%s': shape mismatch (got %lld x %lld, want %lld x %lld)", hf_name,
+                    (long long)rows, (long long)cols, (long long)t.full_rows, (long long)t.full_cols);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)t.rows * t.cols;
+    if (t.kind == Target::F32VEC) {
+        std::vector<float> tmp(n);
+        for (size_t i = 0; i < n; ++i) {
+            if (dtype == NVLLM_DTYPE_F32) tmp[i] = ((const float*)host_data)[i];
+            else { uint32_t u = (uint32_t)((const uint16_t*)host_data)[i] << 16; memcpy(&tmp[i], &u, 4); }
+        }
+        HIPCHK(ctx, hipMemcpy(t.f, tmp.data(), n * 4, hipMemcpyHostToDevice));
+    } else {
+        std::vector<uint16_t> tmp(n);
+        for (int64_t r = 0; r < t.rows; ++r)
+            for (int64_t c = 0; c < t.cols; ++c) {
+                const size_t si = (size_t)(t.r0 + r) * t.full_cols + (t.c0 + c);
+                tmp[(size_t)r * t.cols + c] = dtype == NVLLM_DTYPE_F32 ? host_f32_to_bf16(((const float*)host_data)[si])
+                                                                        : ((const uint16_t*)host_data)[si];
+            }
+        if (t.kind == Target::BF16ROWS) {
+            HIPCHK(ctx, hipMemcpy(t.b, tmp.data(), n * 2, hipMemcpyHostToDevice));
+        } else {
+            if (t.cols != t.w->K) return fail(ctx, NVLLM_EINVAL, "internal: K mismatch for %s", hf_name);
+            bf16_bits* dtmp = nullptr;
+            HIPCHK(ctx, hipMalloc((void**)&dtmp, n * 2));
+            hipError_t e = hipMemcpy(dtmp, tmp.data(), n * 2, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = launch_pack_rows(*t.w, t.dst_row0, (int)t.rows, dtmp, t.cols, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            (void)hipFree(dtmp);
+            HIPCHK(ctx, e);
+        }
+    }
+    m->loaded[hf_name] = true;
+    return NVLLM_OK;
+}
+
+static int synth_one(nvllm_model* m, const char* name, uint64_t seed) {
+    nvllm_ctx* ctx = m->ctx;
+    Target t;
+    if (!resolve(m, name, t)) return fail(ctx, NVLLM_EINVAL, "internal: bad tensor name %s", name);
+    const uint64_t nh = synth_hash_name(name, seed);
+    if (t.kind == Target::F32VEC) {
+        HIPCHK(ctx, launch_synth_rowmajor_f32(t.f, nh, t.synth_kind, 0, t.cols, ctx->stream));
+    } else if (t.kind == Target::BF16ROWS) {
+        HIPCHK(ctx, launch_synth_rowmajor_bf16(t.b, nh, kSynthMatrix, 0, t.rows * t.cols, ctx->stream));
+    } else {
+        HIPCHK(ctx, launch_synth_packed(*t.w, t.dst_row0, (int)t.rows, nh, t.r0, t.c0, t.full_cols, ctx->stream));
+    }
+    m->loaded[name] = true;
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_model_fill_synthetic(nvllm_model* m, uint64_t seed) {
+    if (!m) return NVLLM_EINVAL;
+    HIPCHK(m->ctx, hipSetDevice(m->ctx->device));
+    int rc = synth_one(m, "model.embed_tokens.weight", seed);
+    if (!rc) rc = synth_one(m, "lm_head.weight", seed);
+    if (!rc) rc = synth_one(m, "model.norm.weight", seed);
+    char name[160];
+    for (int l = 0; l < m->L && !rc; ++l)
+        for (const char* s : kLayerTensors) {
+            snprintf(name, sizeof name, "model.layers.%d.%s", l, s);
+            rc = synth_one(m, name, seed);
+            if (rc) break;
+        }
+    if (rc) return rc;
+    HIPCHK(m->ctx, hipStreamSynchronize(m->ctx->stream));
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_model_finalize(nvllm_model* m) {
+    if (!m) return NVLLM_EINVAL;
+    nvllm_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    char name[160];
+    if (!m->loaded.count("model.embed_tokens.weight")) return fail(ctx, NVLLM_ESTATE, "missing tensor model.embed_tokens.weight");
+    if (!m->loaded.count("model.norm.weight")) return fail(ctx, NVLLM_ESTATE, "missing tensor model.norm.weight");
+    for (int l = 0; l < m->L; ++l)
+        for (const char* s : kLayerTensors) {
+            snprintf(name, sizeof name, "model.layers.%d.%s", l, s);
+            if (!m->loaded.count(name)) return fail(ctx, NVLLM_ESTATE, "missing tensor %s", name);
+        }
+    if (!m->loaded.count("lm_head.weight")) {
+        // tied embeddings: LM head = this rank's vocab rows of the embedding table
+        HIPCHK(ctx, launch_pack_rows(m->lm_head, 0, m->V_l, m->embed + (size_t)ctx->tp_rank * m->V_l * m->H, m->H, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    m->finalized = true;
+    return NVLLM_OK;
+}
+
+extern "C" int64_t nvllm_model_weight_bytes(const nvllm_model* m) {
+    if (!m) return 0;
+    int64_t b = (int64_t)m->lm_head.bytes() + (int64_t)m->H * 4;
+    for (const auto& w : m->layers)
+        b += (int64_t)(w.qkv.bytes() + w.o.bytes() + w.gu.bytes() + w.down.bytes()) + (int64_t)(2 * m->H + 2 * m->hd) * 4;
+    return b;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// KV pool
+// ---------------------------------------------------------------------------------------------------
+extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, int max_seqs, int max_batched_tokens) {
+    if (!m) return NVLLM_EINVAL;
+    nvllm_ctx* ctx = m->ctx;
+    if (block_size != kBlockTokens) return fail(ctx, NVLLM_EINVAL, "block_size must be %d (src/engine/sequence.rs:35)", kBlockTokens);
+    if (num_blocks < 1 || max_seqs < 1 || max_batched_tokens < 1) return fail(ctx, NVLLM_EINVAL, "non-positive pool sizes");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    free_kv(m);
+    m->seqs.clear();
+    m->num_blocks = num_blocks;
+    m->max_seqs = max_seqs;
+    m->max_rows = std::max(max_batched_tokens, 16);
+    const int by_pos = (m->cfg.max_position_embeddings + kBlockTokens - 1) / kBlockTokens;
+    m->max_blocks = std::max(1, std::min(num_blocks, by_pos));
+    const size_t per_layer = (size_t)num_blocks * m->kv_l * kBlockTokens * m->hd;
+    m->kcache.assign(m->L, nullptr);
+    m->vcache.assign(m->L, nullptr);
+    for (int l = 0; l < m->L; ++l) {
+        HIPCHK(ctx, hipMalloc((void**)&m->kcache[l], per_layer * 2));
+        HIPCHK(ctx, hipMalloc((void**)&m->vcache[l], per_layer * 2));
+        // zero once: masked lanes multiply P = 0 with whatever the block holds; 0 * finite = 0 needs finite data
+        HIPCHK(ctx, hipMemsetAsync(m->kcache[l], 0, per_layer * 2, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(m->vcache[l], 0, per_layer * 2, ctx->stream));
+    }
+    m->free_blocks.resize(num_blocks);
+    for (int i = 0; i < num_blocks; ++i) m->free_blocks[i] = num_blocks - 1 - i;  // pop_back hands out 0,1,2,...
+    m->free_slots.resize(max_seqs);
+    for (int i = 0; i < max_seqs; ++i) m->free_slots[i] = max_seqs - 1 - i;
+    m->h_block_tables.assign((size_t)max_seqs * m->max_blocks, 0);
+    int rc = dmalloc(ctx, &m->d_block_tables, (size_t)max_seqs * m->max_blocks);
+    HIPCHK(ctx, hipMemsetAsync(m->d_block_tables, 0, (size_t)max_seqs * m->max_blocks * 4, ctx->stream));
+    const size_t R = m->max_rows;
+    const size_t wide = std::max<size_t>({(size_t)m->H, (size_t)m->nh_l * m->hd, (size_t)m->I_l});
+    const size_t nmax = std::max<size_t>({(size_t)(m->nh_l + 2 * m->kv_l) * m->hd, (size_t)m->H, (size_t)2 * m->I_l});
+    m->slab_floats = std::max<size_t>(R * nmax, (size_t)8 * std::min<size_t>(R, 128) * nmax);
+    if (!rc) rc = dmalloc(ctx, &m->d_ids, R);
+    if (!rc) rc = dmalloc(ctx, &m->d_pos, R);
+    if (!rc) rc = dmalloc(ctx, &m->d_slot, R);
+    if (!rc) rc = dmalloc(ctx, &m->d_tile_row0, R);
+    if (!rc) rc = dmalloc(ctx, &m->d_tile_nrows, R);
+    if (!rc) rc = dmalloc(ctx, &m->d_tile_slot, R);
+    if (!rc) rc = dmalloc(ctx, &m->d_last_rows, (size_t)max_seqs);
+    if (!rc) rc = dmalloc(ctx, &m->resid, R * m->H);
+    if (!rc) rc = dmalloc(ctx, &m->slabs, m->slab_floats);
+    if (!rc) rc = dmalloc(ctx, &m->qbuf, R * m->nh_l * m->hd);
+    if (!rc) rc = dmalloc(ctx, &m->red, R * m->H);
+    if (!rc) rc = dmalloc(ctx, &m->logits, (size_t)max_seqs * m->cfg.vocab_size);  // full vocab: TP gathers here
+    if (!rc) rc = dmalloc(ctx, &m->d_maxval, (size_t)max_seqs * std::max(1, ctx->tp_size) * 2);
+    if (!rc) rc = dmalloc(ctx, &m->xh, R * wide);
+    if (!rc) rc = dmalloc(ctx, &m->xl, R * wide);
+    if (!rc) rc = dmalloc(ctx, &m->d_next, (size_t)max_seqs * (ctx->tp_size + 1));
+    if (rc) return rc;
+    m->h_stage_bytes = (R * 6 + (size_t)max_seqs * 4) * sizeof(int) + 256;
+    HIPCHK(ctx, hipHostMalloc(&m->h_stage, m->h_stage_bytes, hipHostMallocDefault));
+    // RoPE table: rotary_embedding.rs:56-80 (f32: inv_freq = 1/base^(2j/hd); angle = pos * inv_freq)
+    m->rope_len = std::min(m->cfg.max_position_embeddings, m->max_blocks * kBlockTokens);
+    const int half = m->hd / 2;
+    std::vector<float> hc((size_t)m->rope_len * half), hs((size_t)m->rope_len * half);
+    const float base = (float)m->cfg.rope_theta;  // "rope_theta as f32", qwen3.rs:135,196
+    for (int j = 0; j < half; ++j) {
+        const float exponent = (2.0f * (float)j) / (float)m->hd;
+        const float inv_freq = 1.0f / powf(base, exponent);
+        for (int p = 0; p < m->rope_len; ++p) {
+            const float ang = (float)p * inv_freq;
+            hc[(size_t)p * half + j] = cosf(ang);
+            hs[(size_t)p * half + j] = sinf(ang);
+        }
+    }
+    rc = dmalloc(ctx, &m->cosv, hc.size());
+    if (!rc) rc = dmalloc(ctx, &m->sinv, hs.size());
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(m->cosv, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(m->sinv, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_kv_num_free_blocks(const nvllm_model* m) { return m ? (int)m->free_blocks.size() : 0; }
+extern "C" int64_t nvllm_kv_bytes_per_token(const nvllm_model* m) {
+    return m ? (int64_t)2 * m->kv_l * m->hd * 2 * m->L : 0;
+}
+
+static void release_seq(nvllm_model* m, SeqState& s) {
+    for (int b : s.blocks) m->free_blocks.push_back(b);
+    s.blocks.clear();
+    s.cached = 0;
+}
+
+extern "C" int nvllm_seq_free(nvllm_model* m, int64_t seq_id) {
+    if (!m) return NVLLM_EINVAL;
+    auto it = m->seqs.find(seq_id);
+    if (it == m->seqs.end()) return NVLLM_OK;
+    release_seq(m, it->second);
+    m->free_slots.push_back(it->second.slot);
+    m->seqs.erase(it);
+    m->last_ids.clear();
+    m->decode_resident = false;
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_debug_enable_taps(nvllm_model* m, int enable) {
+    if (!m) return NVLLM_EINVAL;
+    if (enable && !m->tap_h) {
+        if (!m->max_rows) return fail(m->ctx, NVLLM_ESTATE, "kv_alloc first");
+        int rc = dmalloc(m->ctx, &m->tap_h, (size_t)m->L * m->max_rows * m->H);
+        if (!rc) rc = dmalloc(m->ctx, &m->tap_res, (size_t)m->L * m->max_rows * m->H);
+        if (rc) return rc;
+    }
+    m->taps = enable != 0;
+    return NVLLM_OK;
+}
+extern "C" int nvllm_debug_layer_tap(nvllm_model* m, int layer, int what, float* out, int64_t capacity_floats) {
+    if (!m || !out) return NVLLM_EINVAL;
+    if (!m->tap_h || layer < 0 || layer >= m->L) return fail(m->ctx, NVLLM_ESTATE, "taps not enabled or bad layer");
+    const size_t n = (size_t)m->tap_rows * m->H;
+    if ((int64_t)n > capacity_floats) return fail(m->ctx, NVLLM_EINVAL, "tap needs %zu floats", n);
+    const float* src = (what ? m->tap_res : m->tap_h) + (size_t)layer * m->max_rows * m->H;
+    HIPCHK(m->ctx, hipMemcpy(out, src, n * 4, hipMemcpyDeviceToHost));
+    return NVLLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward over one chunk of rows (all layers)
+// ---------------------------------------------------------------------------------------------------
+// Sum split-K slabs into m->red and all-reduce across the TP group; returns the buffer the next
+// norm should read (with n_slabs = 1).  Row-parallel outputs only (o_proj, down_proj): the
+// all-reduce the reference's RowParallelLinear lacks (src/layers/linear.rs:184-198).
+static int tp_reduce(nvllm_model* m, int rows, int ns, const float** in, int* n_slabs) {
+    nvllm_ctx* ctx = m->ctx;
+    if (ctx->tp_size == 1) { *in = m->slabs; *n_slabs = ns; return NVLLM_OK; }
+    HIPCHK(ctx, launch_slab_sum(m->slabs, ns, (int64_t)rows * m->H, nullptr, rows, m->H, m->red, ctx->stream));
+    NCCLCHK(ctx, ncclAllReduce(m->red, m->red, (size_t)rows * m->H, ncclFloat, ncclSum, ctx->comm, ctx->stream));
+    *in = m->red;
+    *n_slabs = 1;
+    return NVLLM_OK;
+}
+
+// rows R (ids/pos/slot/tiles already on the device), n_last rows listed in d_last_rows -> logits rows
+static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last, int logits_row0) {
+    nvllm_ctx* ctx = m->ctx;
+    hipStream_t s = ctx->stream;
+    const int H = m->H, hd = m->hd;
+    const float eps = (float)m->cfg.rms_norm_eps;
+    const int NQ = (m->nh_l + 2 * m->kv_l) * hd;
+    const float* prev = nullptr;  // output of the previous layer's MLP (slabs or reduced)
+    int prev_ns = 1;
+    m->tap_rows = R;
+    for (int l = 0; l < m->L; ++l) {
+        const LayerW& w = m->layers[l];
+        NormArgs na;
+        na.weight = w.ln1; na.eps = eps; na.H = H; na.xh = m->xh; na.xl = m->xl; na.residual_out = m->resid;
+        if (l == 0) {  // residual None: normed = norm(x), residual = x  (qwen3.rs:382-386)
+            na.ids = m->d_ids; na.embed = m->embed;
+        } else {       // qwen3.rs:378
+            na.in = prev; na.n_slabs = prev_ns; na.slab_stride = (int64_t)R * H; na.residual_in = m->resid;
+        }
+        HIPCHK(ctx, launch_add_rmsnorm(na, R, s));
+        // QKV projection (qwen3.rs:205)
+        GemmPlan pq = plan_gemm(R, NQ, H, 8);
+        HIPCHK(ctx, launch_gemm(pq, m->xh, m->xl, H, w.qkv, m->slabs, R, s));
+        QkvArgs qa;
+        qa.qkv = m->slabs; qa.n_slabs = pq.n_split; qa.slab_stride = (int64_t)R * NQ; qa.qn = w.qn; qa.kn = w.kn; qa.eps = eps;
+        qa.cos = m->cosv; qa.sin = m->sinv; qa.pos = m->d_pos; qa.slot = m->d_slot; qa.block_tables = m->d_block_tables;
+        qa.max_blocks = m->max_blocks; qa.nh_l = m->nh_l;
+        qa.q_scale = powf((float)hd, -0.5f) * 1.4426950408889634f;  // head_dim^-0.5 (qwen3.rs:134) * log2(e)
+        qa.q_out = m->qbuf;
+        qa.kv.k = m->kcache[l]; qa.kv.v = m->vcache[l]; qa.kv.kv_l = m->kv_l; qa.kv.hd = hd;
+        HIPCHK(ctx, launch_qk_norm_rope_kvwrite(qa, R, s));
+        AttnArgs aa;
+        aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
+        aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
+        aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->xh; aa.out_lo = m->xl;
+        HIPCHK(ctx, launch_attn_paged(aa, n_tiles, qt, s));
+        // output projection (qwen3.rs:278) + TP all-reduce
+        const int KO = m->nh_l * hd;
+        GemmPlan po = plan_gemm(R, H, KO, 8);
+        HIPCHK(ctx, launch_gemm(po, m->xh, m->xl, KO, w.o, m->slabs, R, s));
+        const float* oin; int ons;
+        int rc = tp_reduce(m, R, po.n_split, &oin, &ons);
+        if (rc) return rc;
+        NormArgs nb;  // post-attention add + norm (qwen3.rs:393)
+        nb.in = oin; nb.n_slabs = ons; nb.slab_stride = (int64_t)R * H; nb.residual_in = m->resid; nb.residual_out = m->resid;
+        nb.weight = w.ln2; nb.eps = eps; nb.H = H; nb.xh = m->xh; nb.xl = m->xl;
+        HIPCHK(ctx, launch_add_rmsnorm(nb, R, s));
+        // MLP (qwen3.rs:323-327)
+        GemmPlan pg = plan_gemm(R, 2 * m->I_l, H, 8);
+        HIPCHK(ctx, launch_gemm(pg, m->xh, m->xl, H, w.gu, m->slabs, R, s));
+        HIPCHK(ctx, launch_silu_mul(m->slabs, pg.n_split, (int64_t)R * 2 * m->I_l, R, m->I_l, m->xh, m->xl, nullptr, s));
+        GemmPlan pd = plan_gemm(R, H, m->I_l, 8);
+        HIPCHK(ctx, launch_gemm(pd, m->xh, m->xl, m->I_l, w.down, m->slabs, R, s));
+        rc = tp_reduce(m, R, pd.n_split, &prev, &prev_ns);
+        if (rc) return rc;
+        if (m->taps) {
+            HIPCHK(ctx, launch_slab_sum(prev, prev_ns, (int64_t)R * H, nullptr, R, H, m->tap_h + (size_t)l * m->max_rows * H, s));
+            HIPCHK(ctx, hipMemcpyAsync(m->tap_res + (size_t)l * m->max_rows * H, m->resid, (size_t)R * H * 4, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    if (n_last > 0) {
+        // final add + norm on the rows that are a sequence's last token only (qwen3.rs:497), then LM head
+        // on those rows (qwen3.rs:542-550 computes all rows; only row len-1 is used, llm_engine.rs:181-183)
+        NormArgs nf;
+        nf.in = prev; nf.n_slabs = prev_ns; nf.slab_stride = (int64_t)R * H; nf.residual_in = m->resid; nf.row_idx = m->d_last_rows;
+        nf.weight = m->norm; nf.eps = eps; nf.H = H; nf.xh = m->xh; nf.xl = m->xl;
+        HIPCHK(ctx, launch_add_rmsnorm(nf, n_last, s));
+        GemmPlan pl = plan_gemm(n_last, m->V_l, H, 1);
+        float* lg = m->logits + (size_t)logits_row0 * m->V_l;  // TP: local shard rows, gathered later
+        HIPCHK(ctx, launch_gemm(pl, m->xh, m->xl, H, m->lm_head, lg, n_last, s));
+    }
+    return NVLLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// step
+// ---------------------------------------------------------------------------------------------------
+static int ensure_blocks(nvllm_model* m, SeqState& s, int len) {
+    const int need = (len + kBlockTokens - 1) / kBlockTokens;
+    if (need > m->max_blocks) return model_fail(m, NVLLM_ENOMEM, "sequence of %d tokens exceeds %d blocks per sequence", len, m->max_blocks);
+    if ((int)s.blocks.size() >= need) return NVLLM_OK;
+    if ((int)m->free_blocks.size() < need - (int)s.blocks.size())
+        return model_fail(m, NVLLM_ENOMEM, "KV pool exhausted (%zu free blocks, need %d more)", m->free_blocks.size(), need - (int)s.blocks.size());
+    while ((int)s.blocks.size() < need) {
+        const int b = m->free_blocks.back();
+        m->free_blocks.pop_back();
+        m->h_block_tables[(size_t)s.slot * m->max_blocks + s.blocks.size()] = b;
+        s.blocks.push_back(b);
+    }
+    return NVLLM_OK;
+}
+
+// greedy ids (and optionally logits) of `n` last rows to the host; handles the vocab-parallel case
+static int finish_logits(nvllm_model* m, int n, uint32_t* next_ids, float* last_logits) {
+    nvllm_ctx* ctx = m->ctx;
+    hipStream_t s = ctx->stream;
+    const int tp = ctx->tp_size, V = m->cfg.vocab_size, Vl = m->V_l;
+    if (tp == 1) {
+        HIPCHK(ctx, launch_argmax(m->logits, n, V, V, m->d_next, nullptr, s));
+        if (next_ids) HIPCHK(ctx, hipMemcpyAsync(next_ids, m->d_next, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        if (last_logits) HIPCHK(ctx, hipMemcpyAsync(last_logits, m->logits, (size_t)n * V * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        return NVLLM_OK;
+    }
+    // local (max, idx) -> all-gather -> pick the best; ties go to the higher global index
+    uint32_t* idx_all = m->d_next + n;           // [tp][n] lives after the first n entries
+    float* val_all = m->d_maxval;                // [tp][n]
+    HIPCHK(ctx, launch_argmax(m->logits, n, Vl, Vl, idx_all + (size_t)ctx->tp_rank * n, val_all + (size_t)ctx->tp_rank * n, s));
+    NCCLCHK(ctx, ncclAllGather(idx_all + (size_t)ctx->tp_rank * n, idx_all, n, ncclUint32, ctx->comm, s));
+    NCCLCHK(ctx, ncclAllGather(val_all + (size_t)ctx->tp_rank * n, val_all, n, ncclFloat, ctx->comm, s));
+    std::vector<uint32_t> hi((size_t)tp * n);
+    std::vector<float> hv((size_t)tp * n);
+    HIPCHK(ctx, hipMemcpyAsync(hi.data(), idx_all, hi.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(hv.data(), val_all, hv.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    std::vector<uint32_t> best(n);
+    for (int i = 0; i < n; ++i) {
+        float bv = -INFINITY; uint32_t bi = 0;
+        for (int r = 0; r < tp; ++r) {
+            const float v = hv[(size_t)r * n + i];
+            const uint32_t gi = hi[(size_t)r * n + i] + (uint32_t)r * Vl;
+            if (r == 0 || v > bv || (v == bv && gi > bi)) { bv = v; bi = gi; }
+        }
+        best[i] = bi;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(m->d_next, best.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (next_ids) memcpy(next_ids, best.data(), (size_t)n * 4);
+    if (last_logits) {
+        // every rank sends its [n][Vl] shard; host interleaves into [n][V]
+        std::vector<float> shard((size_t)tp * n * Vl);
+        float* dall = nullptr;
+        HIPCHK(ctx, hipMalloc((void**)&dall, shard.size() * 4));
+        ncclResult_t r = ncclAllGather(m->logits, dall, (size_t)n * Vl, ncclFloat, ctx->comm, s);
+        hipError_t e = r == ncclSuccess ? hipMemcpyAsync(shard.data(), dall, shard.size() * 4, hipMemcpyDeviceToHost, s) : hipErrorUnknown;
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(dall);
+        if (r != ncclSuccess) return fail(ctx, NVLLM_ERCCL, "ncclAllGather(logits) -> %s", ncclGetErrorString(r));
+        HIPCHK(ctx, e);
+        for (int rk = 0; rk < tp; ++rk)
+            for (int i = 0; i < n; ++i)
+                memcpy(last_logits + (size_t)i * V + (size_t)rk * Vl, shard.data() + ((size_t)rk * n + i) * Vl, (size_t)Vl * 4);
+    }
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return NVLLM_OK;
+}
+
+struct RowPlan {
+    std::vector<uint32_t> ids;
+    std::vector<int> pos, slot, tile_row0, tile_nrows, tile_slot, last_rows;
+};
+
+// upload one chunk's metadata through the pinned staging buffer (one H2D copy per array kind)
+static int upload_chunk(nvllm_model* m, const RowPlan& p, int r0, int R, int t0, int T, const std::vector<int>& last_local) {
+    nvllm_ctx* ctx = m->ctx;
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipStreamSynchronize(s));  // staging buffer reuse
+    int* st = (int*)m->h_stage;
+    int* h_ids = st; int* h_pos = st + R; int* h_slot = st + 2 * R;
+    int* h_t0 = st + 3 * R; int* h_tn = h_t0 + T; int* h_ts = h_tn + T; int* h_last = h_ts + T;
+    memcpy(h_ids, p.ids.data() + r0, (size_t)R * 4);
+    memcpy(h_pos, p.pos.data() + r0, (size_t)R * 4);
+    memcpy(h_slot, p.slot.data() + r0, (size_t)R * 4);
+    for (int i = 0; i < T; ++i) { h_t0[i] = p.tile_row0[t0 + i] - r0; h_tn[i] = p.tile_nrows[t0 + i]; h_ts[i] = p.tile_slot[t0 + i]; }
+    for (size_t i = 0; i < last_local.size(); ++i) h_last[i] = last_local[i];
+    HIPCHK(ctx, hipMemcpyAsync(m->d_ids, h_ids, (size_t)R * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(m->d_pos, h_pos, (size_t)R * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(m->d_slot, h_slot, (size_t)R * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(m->d_tile_row0, h_t0, (size_t)T * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(m->d_tile_nrows, h_tn, (size_t)T * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(m->d_tile_slot, h_ts, (size_t)T * 4, hipMemcpyHostToDevice, s));
+    if (!last_local.empty())
+        HIPCHK(ctx, hipMemcpyAsync(m->d_last_rows, h_last, last_local.size() * 4, hipMemcpyHostToDevice, s));
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_step(nvllm_model* m, int n_seqs, const int64_t* seq_ids, const uint32_t* const* tokens,
+                          const int32_t* lens, int is_prefill, uint32_t* next_ids, float* last_logits) {
+    if (!m) return NVLLM_EINVAL;
+    nvllm_ctx* ctx = m->ctx;
+    if (!m->finalized) return fail(ctx, NVLLM_ESTATE, "nvllm_model_finalize not called");
+    if (!m->num_blocks) return fail(ctx, NVLLM_ESTATE, "nvllm_kv_alloc not called");
+    if (n_seqs == 0) return NVLLM_OK;  // llm_engine.rs:147-149
+    if (n_seqs < 0 || !seq_ids || !tokens || !lens) return fail(ctx, NVLLM_EINVAL, "bad step arguments");
+    if (n_seqs > m->max_seqs) return fail(ctx, NVLLM_EINVAL, "%d sequences > max_seqs %d", n_seqs, m->max_seqs);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n_seqs; ++i) {
+        if (lens[i] < 1) return fail(ctx, NVLLM_EINVAL, "sequence %d is empty", i);
+        if (lens[i] > m->rope_len) return fail(ctx, NVLLM_EINVAL, "sequence %d: %d tokens > max positions %d", i, lens[i], m->rope_len);
+        for (int t = 0; t < lens[i]; ++t)
+            if (tokens[i][t] >= (uint32_t)m->cfg.vocab_size) return fail(ctx, NVLLM_EINVAL, "sequence %d: token id %u out of range", i, tokens[i][t]);
+        for (int j = 0; j < i; ++j)
+            if (seq_ids[j] == seq_ids[i]) return fail(ctx, NVLLM_EINVAL, "duplicate seq_id in one step");
+    }
+    // sequence bookkeeping + block allocation (the part BlockManager::allocate/may_append leave undone)
+    std::vector<int> start(n_seqs);
+    int new_slots = 0;
+    for (int i = 0; i < n_seqs; ++i) if (!m->seqs.count(seq_ids[i])) ++new_slots;
+    if (new_slots > (int)m->free_slots.size()) return fail(ctx, NVLLM_ENOMEM, "no free sequence slots (max_seqs %d)", m->max_seqs);
+    for (int i = 0; i < n_seqs; ++i) {
+        auto it = m->seqs.find(seq_ids[i]);
+        if (it == m->seqs.end()) {
+            SeqState s;
+            s.slot = m->free_slots.back();
+            m->free_slots.pop_back();
+            it = m->seqs.emplace(seq_ids[i], s).first;
+        } else if (is_prefill) {
+            release_seq(m, it->second);
+        }
+        SeqState& s = it->second;
+        if (s.cached >= lens[i]) s.cached = lens[i] - 1;  // nothing new: recompute the last token
+        start[i] = s.cached;
+        int rc = ensure_blocks(m, s, lens[i]);
+        if (rc) return rc;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(m->d_block_tables, m->h_block_tables.data(), m->h_block_tables.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    // rows and q-tiles
+    RowPlan p;
+    bool all_single = true;
+    for (int i = 0; i < n_seqs; ++i) if (lens[i] - start[i] != 1) all_single = false;
+    const int qt = all_single ? 1 : 2;
+    const int tpt = attn_tokens_per_tile(m->gqa, qt);
+    std::vector<int> seq_last_row(n_seqs);
+    for (int i = 0; i < n_seqs; ++i) {
+        const int slot = m->seqs[seq_ids[i]].slot;
+        for (int t = start[i]; t < lens[i]; ++t) {
+            p.ids.push_back(tokens[i][t]); p.pos.push_back(t); p.slot.push_back(slot);
+        }
+        seq_last_row[i] = (int)p.ids.size() - 1;
+    }
+    const int total_rows = (int)p.ids.size();
+    // chunks of <= max_rows rows; tiles never cross a chunk or a sequence
+    int64_t kv_read_tokens = 0;
+    for (int i = 0; i < n_seqs; ++i) kv_read_tokens += lens[i];
+    int r0 = 0, logits_row = 0;
+    std::vector<int> row_seq(total_rows);
+    { int r = 0; for (int i = 0; i < n_seqs; ++i) for (int t = start[i]; t < lens[i]; ++t) row_seq[r++] = i; }
+    while (r0 < total_rows) {
+        const int R = std::min(m->max_rows, total_rows - r0);
+        p.tile_row0.clear(); p.tile_nrows.clear(); p.tile_slot.clear();
+        int r = r0;
+        while (r < r0 + R) {
+            int e = r;
+            while (e < r0 + R && e - r < tpt && row_seq[e] == row_seq[r]) ++e;
+            p.tile_row0.push_back(r); p.tile_nrows.push_back(e - r); p.tile_slot.push_back(p.slot[r]);
+            r = e;
+        }
+        std::vector<int> last_local;
+        for (int i = 0; i < n_seqs; ++i)
+            if (seq_last_row[i] >= r0 && seq_last_row[i] < r0 + R) last_local.push_back(seq_last_row[i] - r0);
+        int rc = upload_chunk(m, p, r0, R, 0, (int)p.tile_row0.size(), last_local);
+        if (rc) return rc;
+        rc = forward_chunk(m, R, (int)p.tile_row0.size(), qt, (int)last_local.size(), logits_row);
+        if (rc) return rc;
+        logits_row += (int)last_local.size();
+        r0 += R;
+    }
+    int rc = finish_logits(m, n_seqs, next_ids, last_logits);
+    if (rc) return rc;
+    m->last_ids.assign(seq_ids, seq_ids + n_seqs);
+    m->last_lens.assign(lens, lens + n_seqs);
+    m->decode_resident = all_single && total_rows <= m->max_rows;
+    for (int i = 0; i < n_seqs; ++i) m->seqs[seq_ids[i]].cached = lens[i];
+    m->last_bytes = nvllm_model_weight_bytes(m) + kv_read_tokens * nvllm_kv_bytes_per_token(m) +
+                    (last_logits ? (int64_t)4 * n_seqs * m->cfg.vocab_size : 0);
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_decode_next(nvllm_model* m, uint32_t* next_ids) {
+    if (!m) return NVLLM_EINVAL;
+    nvllm_ctx* ctx = m->ctx;
+    const int n = (int)m->last_ids.size();
+    if (n == 0) return fail(ctx, NVLLM_ESTATE, "no previous step to continue");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    bool table_dirty = false;
+    for (int i = 0; i < n; ++i) {
+        SeqState& st = m->seqs[m->last_ids[i]];
+        const int len = m->last_lens[i] + 1;
+        if (len > m->rope_len) return fail(ctx, NVLLM_EINVAL, "sequence %d would exceed max positions %d", i, m->rope_len);
+        const size_t before = st.blocks.size();
+        int rc = ensure_blocks(m, st, len);
+        if (rc) return rc;
+        table_dirty |= st.blocks.size() != before;
+    }
+    if (table_dirty)
+        HIPCHK(ctx, hipMemcpyAsync(m->d_block_tables, m->h_block_tables.data(), m->h_block_tables.size() * 4, hipMemcpyHostToDevice, s));
+    if (m->decode_resident) {
+        // ids <- last greedy ids, pos += 1: the batch metadata is already on the device
+        HIPCHK(ctx, launch_advance_decode(m->d_ids, m->d_next, m->d_pos, n, s));
+    } else {
+        // previous step was a prefill (or a multi-chunk step): rebuild decode metadata once
+        RowPlan p;
+        std::vector<int> last_local(n);
+        for (int i = 0; i < n; ++i) {
+            const SeqState& st = m->seqs[m->last_ids[i]];
+            p.ids.push_back(0); p.pos.push_back(m->last_lens[i]); p.slot.push_back(st.slot);
+            p.tile_row0.push_back(i); p.tile_nrows.push_back(1); p.tile_slot.push_back(st.slot);
+            last_local[i] = i;
+        }
+        int rc0 = upload_chunk(m, p, 0, n, 0, n, last_local);
+        if (rc0) return rc0;
+        HIPCHK(ctx, hipMemcpyAsync(m->d_ids, m->d_next, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        m->decode_resident = true;
+    }
+    int rc = forward_chunk(m, n, n, 1, n, 0);
+    if (rc) return rc;
+    rc = finish_logits(m, n, next_ids, nullptr);
+    if (rc) return rc;
+    int64_t kv_tokens = 0;
+    for (int i = 0; i < n; ++i) {
+        m->last_lens[i] += 1;
+        m->seqs[m->last_ids[i]].cached = m->last_lens[i];
+        kv_tokens += m->last_lens[i];
+    }
+    m->last_bytes = nvllm_model_weight_bytes(m) + kv_tokens * nvllm_kv_bytes_per_token(m);
+    return NVLLM_OK;
+}
+
+extern "C" int64_t nvllm_last_step_bytes(const nvllm_model* m) { return m ? m->last_bytes : 0; }
+
+// ---------------------------------------------------------------------------------------------------
+// fine seam: single ops on raw device pointers (layer-level parity tests; src/layers/*.rs surface)
+// ---------------------------------------------------------------------------------------------------
+struct nvllm_weight {
+    PackedW w;     // padded: N to 16, K to 32 (zeros)
+    int N = 0, K = 0;  // logical
+};
+
+struct TmpBufs {  // frees on scope exit (after a stream sync done by the caller)
+    std::vector<void*> p;
+    ~TmpBufs() { for (void* q : p) (void)hipFree(q); }
+    template <typename T>
+    hipError_t get(T** out, size_t count) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, std::max<size_t>(count * sizeof(T), 16));
+        if (e == hipSuccess) { p.push_back(q); *out = (T*)q; }
+        return e;
+    }
+};
+
+extern "C" int nvllm_op_pack_weight(nvllm_ctx* ctx, const void* host_w, int dtype, int N, int K, nvllm_weight** out) {
+    if (!ctx || !host_w || !out || N < 1 || K < 1) return fail(ctx, NVLLM_EINVAL, "bad pack_weight arguments");
+    if (dtype != NVLLM_DTYPE_F32 && dtype != NVLLM_DTYPE_BF16) return fail(ctx, NVLLM_EINVAL, "dtype %d unsupported", dtype);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int Np = (N + 15) / 16 * 16, Kp = (K + 31) / 32 * 32;
+    std::vector<uint16_t> tmp((size_t)Np * Kp, 0);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k)
+            tmp[(size_t)n * Kp + k] = dtype == NVLLM_DTYPE_F32 ? host_f32_to_bf16(((const float*)host_w)[(size_t)n * K + k])
+                                                               : ((const uint16_t*)host_w)[(size_t)n * K + k];
+    nvllm_weight* w = new nvllm_weight();
+    w->N = N; w->K = K; w->w.N = Np; w->w.K = Kp;
+    bf16_bits* dtmp = nullptr;
+    hipError_t e = hipMalloc((void**)&w->w.data, w->w.bytes());
+    if (e == hipSuccess) e = hipMalloc((void**)&dtmp, tmp.size() * 2);
+    if (e == hipSuccess) e = hipMemcpy(dtmp, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_pack_rows(w->w, 0, Np, dtmp, Kp, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (dtmp) (void)hipFree(dtmp);
+    if (e != hipSuccess) { if (w->w.data) (void)hipFree(w->w.data); delete w; HIPCHK(ctx, e); }
+    *out = w;
+    return NVLLM_OK;
+}
+extern "C" int nvllm_op_free_weight(nvllm_ctx* ctx, nvllm_weight* w) {
+    if (!w) return NVLLM_OK;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(w->w.data);
+    delete w;
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_op_linear(nvllm_ctx* ctx, const float* x, const nvllm_weight* w, const float* bias, int M, float* y) {
+    if (!ctx || !x || !w || !y || M < 1) return fail(ctx, NVLLM_EINVAL, "bad linear arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    TmpBufs t;
+    bf16_bits *hi, *lo;
+    float* slabs;
+    const int Kp = w->w.K, Np = w->w.N;
+    GemmPlan p = plan_gemm(M, Np, Kp, 8);
+    HIPCHK(ctx, t.get(&hi, (size_t)M * Kp));
+    HIPCHK(ctx, t.get(&lo, (size_t)M * Kp));
+    HIPCHK(ctx, t.get(&slabs, (size_t)p.n_split * M * Np));
+    HIPCHK(ctx, launch_split_hilo_pad(x, M, w->K, Kp, hi, lo, s));
+    HIPCHK(ctx, launch_gemm(p, hi, lo, Kp, w->w, slabs, M, s));
+    HIPCHK(ctx, launch_slab_sum_ld(slabs, p.n_split, (int64_t)M * Np, Np, bias, M, w->N, y, w->N, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_op_rmsnorm(nvllm_ctx* ctx, const float* x, const float* residual, const float* weight, double eps,
+                                int rows, int n, float* y, float* residual_out) {
+    if (!ctx || !x || !weight || !y || rows < 1 || n < 1) return fail(ctx, NVLLM_EINVAL, "bad rmsnorm arguments");
+    if ((residual == nullptr) != (residual_out == nullptr)) return fail(ctx, NVLLM_EINVAL, "residual and residual_out go together");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n % 4 == 0 && n <= 8192) {  // the kernel the step path uses
+        NormArgs a;
+        a.in = x; a.residual_in = residual; a.residual_out = residual_out; a.weight = weight; a.eps = (float)eps; a.H = n; a.y = y;
+        HIPCHK(ctx, launch_add_rmsnorm(a, rows, ctx->stream));
+    } else {
+        HIPCHK(ctx, launch_rmsnorm_generic(x, residual, weight, (float)eps, rows, n, y, residual_out, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_op_silu_mul(nvllm_ctx* ctx, const float* x, int rows, int n, float* y) {
+    if (!ctx || !x || !y || rows < 1 || n < 1) return fail(ctx, NVLLM_EINVAL, "bad silu_mul arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n % 4 == 0) HIPCHK(ctx, launch_silu_mul(x, 1, 0, rows, n, nullptr, nullptr, y, ctx->stream));
+    else HIPCHK(ctx, launch_silu_mul_generic(x, rows, n, y, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NVLLM_OK;
+}
+
+static void host_rope_table(int hd, float base, int T, std::vector<float>& hc, std::vector<float>& hs) {
+    const int half = hd / 2;
+    hc.resize((size_t)T * half); hs.resize((size_t)T * half);
+    for (int j = 0; j < half; ++j) {
+        const float inv_freq = 1.0f / powf(base, (2.0f * (float)j) / (float)hd);
+        for (int p = 0; p < T; ++p) {
+            const float ang = (float)p * inv_freq;
+            hc[(size_t)p * half + j] = cosf(ang);
+            hs[(size_t)p * half + j] = sinf(ang);
+        }
+    }
+}
+
+extern "C" int nvllm_op_rope(nvllm_ctx* ctx, float* q, float* k, int B, int nh, int kv, int T, int hd, float base) {
+    if (!ctx || !q || !k || B < 1 || nh < 1 || kv < 1 || T < 1 || hd < 2 || hd % 2) return fail(ctx, NVLLM_EINVAL, "bad rope arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<float> hc, hs;
+    host_rope_table(hd, base, T, hc, hs);
+    TmpBufs t;
+    float *dc, *ds;
+    HIPCHK(ctx, t.get(&dc, hc.size()));
+    HIPCHK(ctx, t.get(&ds, hs.size()));
+    HIPCHK(ctx, hipMemcpyAsync(dc, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ds, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, launch_rope_bhtd(q, B, nh, T, hd, dc, ds, ctx->stream));
+    HIPCHK(ctx, launch_rope_bhtd(k, B, kv, T, hd, dc, ds, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_op_attention(nvllm_ctx* ctx, const float* q, const float* k, const float* v, int B, int nh, int kv,
+                                  int T, int hd, float scale, float* out) {
+    if (!ctx || !q || !k || !v || !out || B < 1 || T < 1) return fail(ctx, NVLLM_EINVAL, "bad attention arguments");
+    if (hd != 64 && hd != 128) return fail(ctx, NVLLM_EINVAL, "head_dim %d unsupported (64 or 128)", hd);
+    if (nh % kv || nh / kv > 16) return fail(ctx, NVLLM_EINVAL, "bad GQA shape");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int gqa = nh / kv, rows = B * T, bps = (T + kBlockTokens - 1) / kBlockTokens, nblk = B * bps;
+    TmpBufs t;
+    float *qr, *kr, *vr;
+    int *dpos, *dslot, *dbt, *dt0, *dtn, *dts;
+    KvLayout kvl;
+    kvl.kv_l = kv; kvl.hd = hd;
+    const size_t cache_elems = (size_t)nblk * kv * kBlockTokens * hd;
+    HIPCHK(ctx, t.get(&qr, (size_t)rows * nh * hd));
+    HIPCHK(ctx, t.get(&kr, (size_t)rows * kv * hd));
+    HIPCHK(ctx, t.get(&vr, (size_t)rows * kv * hd));
+    HIPCHK(ctx, t.get(&kvl.k, cache_elems));
+    HIPCHK(ctx, t.get(&kvl.v, cache_elems));
+    HIPCHK(ctx, hipMemsetAsync(kvl.k, 0, cache_elems * 2, s));
+    HIPCHK(ctx, hipMemsetAsync(kvl.v, 0, cache_elems * 2, s));
+    const int qt = 2, tpt = attn_tokens_per_tile(gqa, qt);
+    std::vector<int> hpos(rows), hslot(rows), hbt(nblk), ht0, htn, hts;
+    for (int b = 0; b < B; ++b) {
+        for (int tt = 0; tt < T; ++tt) { hpos[b * T + tt] = tt; hslot[b * T + tt] = b; }
+        for (int j = 0; j < bps; ++j) hbt[b * bps + j] = b * bps + j;
+        for (int tt = 0; tt < T; tt += tpt) { ht0.push_back(b * T + tt); htn.push_back(std::min(tpt, T - tt)); hts.push_back(b); }
+    }
+    const int nt = (int)ht0.size();
+    HIPCHK(ctx, t.get(&dpos, rows)); HIPCHK(ctx, t.get(&dslot, rows)); HIPCHK(ctx, t.get(&dbt, nblk));
+    HIPCHK(ctx, t.get(&dt0, nt)); HIPCHK(ctx, t.get(&dtn, nt)); HIPCHK(ctx, t.get(&dts, nt));
+    HIPCHK(ctx, hipMemcpyAsync(dpos, hpos.data(), (size_t)rows * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dslot, hslot.data(), (size_t)rows * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dbt, hbt.data(), (size_t)nblk * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dt0, ht0.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dtn, htn.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dts, hts.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, launch_bhtd_to_rows(q, B, nh, T, hd, scale * 1.4426950408889634f, qr, s));
+    HIPCHK(ctx, launch_bhtd_to_rows(k, B, kv, T, hd, 1.0f, kr, s));
+    HIPCHK(ctx, launch_bhtd_to_rows(v, B, kv, T, hd, 1.0f, vr, s));
+    HIPCHK(ctx, launch_kv_write_plain(kr, vr, rows, dpos, dslot, dbt, bps, kvl, s));
+    AttnArgs a;
+    a.q = qr; a.kv = kvl; a.block_tables = dbt; a.max_blocks = bps; a.tile_row0 = dt0; a.tile_nrows = dtn; a.tile_slot = dts;
+    a.pos = dpos; a.nh_l = nh; a.gqa = gqa; a.out_f32 = out;
+    HIPCHK(ctx, launch_attn_paged(a, nt, qt, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_op_embedding(nvllm_ctx* ctx, const float* table, const uint32_t* ids, int n, int V, int H, float* y) {
+    if (!ctx || !table || !ids || !y || n < 1) return fail(ctx, NVLLM_EINVAL, "bad embedding arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, launch_embedding_f32(table, ids, n, V, H, y, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_op_argmax(nvllm_ctx* ctx, const float* logits, int rows, int V, uint32_t* ids) {
+    if (!ctx || !logits || !ids || rows < 1 || V < 1) return fail(ctx, NVLLM_EINVAL, "bad argmax arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, launch_argmax(logits, rows, V, V, ids, nullptr, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_op_allreduce(nvllm_ctx* ctx, float* buf, int64_t count) {
+    if (!ctx || !buf || count < 0) return fail(ctx, NVLLM_EINVAL, "bad allreduce arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->tp_size > 1) NCCLCHK(ctx, ncclAllReduce(buf, buf, (size_t)count, ncclFloat, ncclSum, ctx->comm, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_op_synth_bf16(nvllm_ctx* ctx, const char* name, uint64_t seed, int kind, int64_t first, int64_t count,
+                                   uint16_t* host_out) {
+    if (!ctx || !name || !host_out || count < 1) return fail(ctx, NVLLM_EINVAL, "bad synth arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    TmpBufs t;
+    bf16_bits* d;
+    HIPCHK(ctx, t.get(&d, (size_t)count));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(d, synth_hash_name(name, seed), kind, first, count, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(host_out, d, (size_t)count * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NVLLM_OK;
+}

@@ -1,0 +1,148 @@
+// Launchers of the hand-written gfx950 kernels (kernels.hip).  Host C++; every launcher enqueues on
+// the given stream and returns hipGetLastError().  Data layouts are documented in DESIGN.md §3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nvllm {
+
+typedef uint16_t bf16_bits;  // raw bf16 storage
+typedef uint16_t f16_bits;   // raw f16 storage
+
+constexpr int kBlockTokens = 256;  // KV block size, fixed by the reference (src/engine/sequence.rs:35)
+
+// ---- packed weight: MFMA 16x16x32 A-fragment tiles -------------------------------------------
+// W[N][K] (row-major, bf16) is stored as [N/16][K/32][64 lanes][8 bf16]; lane l of tile (nt,kt)
+// holds W[nt*16 + (l&15)][kt*32 + 8*(l>>4) + 0..7].  One wave-load = one contiguous 1 KiB tile.
+struct PackedW {
+    uint4* data = nullptr;
+    int N = 0, K = 0;  // logical sizes (N % 16 == 0, K % 32 == 0)
+    size_t bytes() const { return (size_t)N * K * 2; }
+};
+
+// pack rows [row0, row0+rows) of dst from a row-major bf16 source (ld = elements between rows)
+hipError_t launch_pack_rows(const PackedW& dst, int row0, int rows, const bf16_bits* src, int64_t ld, hipStream_t s);
+// generate rows [row0,row0+rows) of dst from the synthetic tensor `name_hash`: logical element
+// (r, k) of the destination = source element (src_row0 + r, src_col0 + k) of a [*, src_ld] tensor
+hipError_t launch_synth_packed(const PackedW& dst, int row0, int rows, uint64_t name_hash, int64_t src_row0,
+                               int64_t src_col0, int64_t src_ld, hipStream_t s);
+// row-major synthetic fill: dst bf16 [count] = elements [first, first+count)
+hipError_t launch_synth_rowmajor_bf16(bf16_bits* dst, uint64_t name_hash, int kind, int64_t first, int64_t count,
+                                      hipStream_t s);
+hipError_t launch_synth_rowmajor_f32(float* dst, uint64_t name_hash, int kind, int64_t first, int64_t count,
+                                     hipStream_t s);
+
+// ---- conversions ---------------------------------------------------------------------------------
+hipError_t launch_f32_to_bf16(const float* src, bf16_bits* dst, int64_t n, hipStream_t s);
+hipError_t launch_bf16_to_f32(const bf16_bits* src, float* dst, int64_t n, hipStream_t s);
+// x f32 [rows][n] -> hi/lo bf16 planes (hi = bf16(x), lo = bf16(x - hi))
+hipError_t launch_split_hilo(const float* x, bf16_bits* hi, bf16_bits* lo, int64_t n, hipStream_t s);
+
+// ---- GEMM: out[ks][M][N] = x[M][K-slice ks] . W[N][K-slice ks]^T  (f32 slabs, ks < n_split) ------
+struct GemmPlan {
+    int mt, nt, nw, kc;  // m-tiles per WG, n-tiles per wave, waves per WG, k-tiles per LDS chunk
+    int n_split;         // K splits across workgroups (slabs)
+    int kt_per_split;
+};
+GemmPlan plan_gemm(int M, int N, int K, int max_split);
+hipError_t launch_gemm(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
+                       float* out, int M, hipStream_t s);
+
+// ---- (embed +) add + RMSNorm ----------------------------------------------------------------------
+struct NormArgs {
+    const float* in = nullptr;        // [n_slabs][rows_in][H] f32 (slab sum) ; or nullptr with ids/embed
+    int n_slabs = 1;
+    int64_t slab_stride = 0;          // floats between slabs
+    const uint32_t* ids = nullptr;    // embedding mode: token id per row
+    const bf16_bits* embed = nullptr; // [V][H] bf16
+    const float* residual_in = nullptr;
+    float* residual_out = nullptr;    // may alias residual_in
+    const int* row_idx = nullptr;     // gather: input row of output row r (outputs are compact)
+    const float* weight = nullptr;
+    float eps = 1e-6f;
+    int H = 0;
+    bf16_bits* xh = nullptr;          // outputs (nullable individually)
+    bf16_bits* xl = nullptr;
+    float* y = nullptr;
+};
+hipError_t launch_add_rmsnorm(const NormArgs& a, int rows, hipStream_t s);
+
+// ---- q/k norm + RoPE + KV cache write -------------------------------------------------------------
+struct KvLayout {
+    f16_bits* k = nullptr;  // [num_blocks][kv_l][256][hd]  f16 row-major
+    f16_bits* v = nullptr;  // [num_blocks][kv_l][8 tiles][hd/16][64 lanes][8] f16 (PV A-fragment packed)
+    int kv_l = 0, hd = 0;
+};
+struct QkvArgs {
+    const float* qkv = nullptr;  // [n_slabs][rows][(nh_l+2kv_l)*hd]
+    int n_slabs = 1;
+    int64_t slab_stride = 0;
+    const float* qn = nullptr;   // [hd]
+    const float* kn = nullptr;
+    float eps = 1e-6f;
+    const float* cos = nullptr;  // [max_pos][hd/2]
+    const float* sin = nullptr;
+    const int* pos = nullptr;    // [rows]
+    const int* slot = nullptr;   // [rows] row -> sequence slot
+    const int* block_tables = nullptr;
+    int max_blocks = 0;
+    int nh_l = 0;
+    float q_scale = 1.f;         // folded into q: head_dim^-0.5 * log2(e)
+    float* q_out = nullptr;      // [rows][nh_l*hd] f32
+    KvLayout kv;
+};
+hipError_t launch_qk_norm_rope_kvwrite(const QkvArgs& a, int rows, hipStream_t s);
+
+// ---- paged attention (prefill tiles and decode rows alike) ----------------------------------------
+struct AttnArgs {
+    const float* q = nullptr;          // [rows][nh_l*hd], already scaled by q_scale
+    KvLayout kv;
+    const int* block_tables = nullptr;
+    int max_blocks = 0;
+    const int* tile_row0 = nullptr;    // per q-tile: first row, #rows, sequence slot
+    const int* tile_nrows = nullptr;
+    const int* tile_slot = nullptr;
+    const int* pos = nullptr;          // [rows]
+    int nh_l = 0, gqa = 1;
+    bf16_bits* out_hi = nullptr;       // [rows][nh_l*hd]
+    bf16_bits* out_lo = nullptr;
+    float* out_f32 = nullptr;          // optional f32 copy (fine-seam op)
+};
+// qt = q sub-tiles (of 16 MFMA rows) per workgroup: 1 (decode) or 2 (prefill)
+hipError_t launch_attn_paged(const AttnArgs& a, int n_tiles, int qt, hipStream_t s);
+inline int attn_tokens_per_tile(int gqa, int qt) { return (16 / gqa) * qt; }
+
+// ---- SwiGLU -----------------------------------------------------------------------------------------
+// gu [n_slabs][rows][2*I] -> act hi/lo [rows][I] (and/or f32 y)
+hipError_t launch_silu_mul(const float* gu, int n_slabs, int64_t slab_stride, int rows, int I, bf16_bits* hi,
+                           bf16_bits* lo, float* y, hipStream_t s);
+
+// ---- misc --------------------------------------------------------------------------------------------
+// y[r][:] = sum_s in[s][r][:] (+ bias)  -- finishes a split-K GEMM for the fine-seam op
+hipError_t launch_slab_sum(const float* in, int n_slabs, int64_t slab_stride, const float* bias, int rows, int N,
+                           float* y, hipStream_t s);
+hipError_t launch_slab_sum_ld(const float* in, int n_slabs, int64_t slab_stride, int64_t ld_in, const float* bias,
+                              int rows, int N, float* y, int64_t ld_out, hipStream_t s);
+// generic-shape fallbacks used only by the fine-seam ops
+hipError_t launch_rmsnorm_generic(const float* x, const float* res, const float* w, float eps, int rows, int n, float* y,
+                                  float* res_out, hipStream_t s);
+hipError_t launch_silu_mul_generic(const float* x, int rows, int n, float* y, hipStream_t s);
+hipError_t launch_split_hilo_pad(const float* x, int rows, int K, int Kpad, bf16_bits* hi, bf16_bits* lo, hipStream_t s);
+// argmax with LAST-max tie rule; idx_offset added to the result (vocab-parallel shards)
+hipError_t launch_argmax(const float* logits, int rows, int V, int64_t ld, uint32_t* ids, float* maxval,
+                         hipStream_t s);
+hipError_t launch_embedding_f32(const float* table, const uint32_t* ids, int n, int V, int H, float* y,
+                                hipStream_t s);
+// fine-seam RoPE on [B,heads,T,hd] f32 in place, positions 0..T
+hipError_t launch_rope_bhtd(float* x, int B, int heads, int T, int hd, const float* cos, const float* sin,
+                            hipStream_t s);
+// [B,heads,T,hd] -> [B*T][heads*hd] (optionally scaled)
+hipError_t launch_bhtd_to_rows(const float* x, int B, int heads, int T, int hd, float scale, float* y,
+                               hipStream_t s);
+// write k,v rows ([rows][kv*hd] f32) into the paged cache at (slot,pos) without norm/rope
+hipError_t launch_kv_write_plain(const float* k, const float* v, int rows, const int* pos, const int* slot,
+                                 const int* block_tables, int max_blocks, KvLayout kv, hipStream_t s);
+// token feedback for nvllm_decode_next: ids[i] = next[i]; pos[i] += 1
+hipError_t launch_advance_decode(uint32_t* ids, const uint32_t* next, int* pos, int n, hipStream_t s);
+
+}  // namespace nvllm

@@ -1,0 +1,911 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels of the Qwen3 forward path.
+//
+// Reference behaviour each kernel replaces is cited at the kernel; layouts are in DESIGN.md §3.
+// MFMA: v_mfma_f32_16x16x32_{bf16,f16}.  Lane l of a wave: l15 = l & 15, grp = l >> 4.
+//   A frag: A[row l15][k = 8*grp + j]      B frag: B[k = 8*grp + j][col l15]      (j = 0..7)
+//   C/D   : D[row 4*grp + reg][col l15]    (reg = 0..3)
+#include "kernels.h"
+#include "synth_device.h"
+
+namespace nvllm {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t bf16_bits_of(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+__device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) {
+    const __bf16 h = (__bf16)x;
+    hi = __builtin_bit_cast(uint16_t, h);
+    lo = __builtin_bit_cast(uint16_t, (__bf16)(x - (float)h));
+}
+__device__ __forceinline__ _Float16 f16_sat(float x) { return (_Float16)fminf(fmaxf(x, -65504.f), 65504.f); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight packing / synthetic fill
+// ---------------------------------------------------------------------------------------------------
+// one thread per 16-byte lane slot of the destination: (dest row r, k-chunk of 8)
+__global__ void __launch_bounds__(256) pack_rows_kernel(uint4* __restrict__ dst, int KT, int row0, int rows,
+                                                        const uint16_t* __restrict__ src, int64_t ld) {
+    const int64_t chunks_per_row = (int64_t)KT * 4;
+    const int64_t total = (int64_t)rows * chunks_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int rl = (int)(i / chunks_per_row);
+        const int kc8 = (int)(i % chunks_per_row);
+        const int r = row0 + rl;
+        const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)rl * ld + (int64_t)kc8 * 8);
+        const int nt = r >> 4, kt = kc8 >> 2, lane = ((kc8 & 3) << 4) | (r & 15);
+        dst[((int64_t)nt * KT + kt) * 64 + lane] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) synth_packed_kernel(uint4* __restrict__ dst, int KT, int row0, int rows,
+                                                           uint64_t name_hash, int64_t src_row0, int64_t src_col0,
+                                                           int64_t src_ld) {
+    const int64_t chunks_per_row = (int64_t)KT * 4;
+    const int64_t total = (int64_t)rows * chunks_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int rl = (int)(i / chunks_per_row);
+        const int kc8 = (int)(i % chunks_per_row);
+        const int r = row0 + rl;
+        const uint64_t base = (uint64_t)(src_row0 + rl) * (uint64_t)src_ld + (uint64_t)(src_col0 + (int64_t)kc8 * 8);
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t a = synth_bits(name_hash, base + 2 * j, kSynthMatrix);
+            const uint32_t b = synth_bits(name_hash, base + 2 * j + 1, kSynthMatrix);
+            w[j] = a | (b << 16);
+        }
+        const int nt = r >> 4, kt = kc8 >> 2, lane = ((kc8 & 3) << 4) | (r & 15);
+        dst[((int64_t)nt * KT + kt) * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+__global__ void __launch_bounds__(256) synth_rowmajor_bf16_kernel(uint16_t* __restrict__ dst, uint64_t name_hash,
+                                                                  int kind, int64_t first, int64_t count) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = synth_bits(name_hash, (uint64_t)(first + i), kind);
+}
+__global__ void __launch_bounds__(256) synth_rowmajor_f32_kernel(float* __restrict__ dst, uint64_t name_hash, int kind,
+                                                                 int64_t first, int64_t count) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = bf16_to_f32(synth_bits(name_hash, (uint64_t)(first + i), kind));
+}
+
+static inline int grid_for(int64_t n, int per_block = 256, int cap = 8192) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+hipError_t launch_pack_rows(const PackedW& dst, int row0, int rows, const bf16_bits* src, int64_t ld, hipStream_t s) {
+    const int KT = dst.K / 32;
+    pack_rows_kernel<<<grid_for((int64_t)rows * KT * 4), 256, 0, s>>>(dst.data, KT, row0, rows, src, ld);
+    return hipGetLastError();
+}
+hipError_t launch_synth_packed(const PackedW& dst, int row0, int rows, uint64_t name_hash, int64_t src_row0,
+                               int64_t src_col0, int64_t src_ld, hipStream_t s) {
+    const int KT = dst.K / 32;
+    synth_packed_kernel<<<grid_for((int64_t)rows * KT * 4), 256, 0, s>>>(dst.data, KT, row0, rows, name_hash, src_row0,
+                                                                        src_col0, src_ld);
+    return hipGetLastError();
+}
+hipError_t launch_synth_rowmajor_bf16(bf16_bits* dst, uint64_t name_hash, int kind, int64_t first, int64_t count,
+                                      hipStream_t s) {
+    synth_rowmajor_bf16_kernel<<<grid_for(count), 256, 0, s>>>(dst, name_hash, kind, first, count);
+    return hipGetLastError();
+}
+hipError_t launch_synth_rowmajor_f32(float* dst, uint64_t name_hash, int kind, int64_t first, int64_t count,
+                                     hipStream_t s) {
+    synth_rowmajor_f32_kernel<<<grid_for(count), 256, 0, s>>>(dst, name_hash, kind, first, count);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conversions
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                                          int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = bf16_bits_of(src[i]);
+}
+__global__ void __launch_bounds__(256) bf16_to_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst,
+                                                          int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = bf16_to_f32(src[i]);
+}
+__global__ void __launch_bounds__(256) split_hilo_kernel(const float* __restrict__ x, uint16_t* __restrict__ hi,
+                                                         uint16_t* __restrict__ lo, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint16_t h, l;
+        split_bf16(x[i], h, l);
+        hi[i] = h;
+        lo[i] = l;
+    }
+}
+hipError_t launch_f32_to_bf16(const float* src, bf16_bits* dst, int64_t n, hipStream_t s) {
+    f32_to_bf16_kernel<<<grid_for(n), 256, 0, s>>>(src, dst, n);
+    return hipGetLastError();
+}
+hipError_t launch_bf16_to_f32(const bf16_bits* src, float* dst, int64_t n, hipStream_t s) {
+    bf16_to_f32_kernel<<<grid_for(n), 256, 0, s>>>(src, dst, n);
+    return hipGetLastError();
+}
+hipError_t launch_split_hilo(const float* x, bf16_bits* hi, bf16_bits* lo, int64_t n, hipStream_t s) {
+    split_hilo_kernel<<<grid_for(n), 256, 0, s>>>(x, hi, lo, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GEMM  out[ks][M][N] = x[M][Kslice] . W[N][Kslice]^T        (replaces candle_nn::Linear::forward,
+// src/layers/linear.rs:35-36,72-77,184-198; src/models/qwen3.rs:205,278,324,326,548)
+//
+// Weight-streaming design: every wave owns NT n-tiles (16 output features each) and streams their
+// packed A-fragments straight from HBM into VGPRs, one contiguous 1 KiB wave-load per (n-tile, k-tile);
+// the activation slice (B operand) is staged once per workgroup through LDS in fragment order and
+// shared by the NW waves.  Activations are bf16 hi + bf16 lo (x = hi + lo to 2^-17), two MFMAs per
+// fragment pair, f32 accumulate: this keeps logits within 1e-3 of the f32 reference.
+// grid = (n-groups, k-splits, m-blocks); k-splits write separate f32 slabs, summed by the consumer.
+// ---------------------------------------------------------------------------------------------------
+template <int MT, int NT, int NW, int KC>
+__global__ void __launch_bounds__(NW * 64)
+gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, int ldx, const uint4* __restrict__ wp,
+            float* __restrict__ out, int M, int N, int KT, int kt_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint4* lds = reinterpret_cast<uint4*>(smem_raw);  // [2 planes][MT][KC][64 lanes]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int ntiles = N >> 4;
+    const int nt0 = (blockIdx.x * NW + wave) * NT;
+    const int kt_begin = blockIdx.y * kt_per_split;
+    const int kt_end = min(KT, kt_begin + kt_per_split);
+    const int m0 = blockIdx.z * (MT * 16);
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kc = kt_begin; kc < kt_end; kc += KC) {
+        const int nk = min(KC, kt_end - kc);
+        // weight fragments of this chunk: global -> VGPR, issued before the LDS staging so they fly meanwhile
+        uint4 wf[NT][KC];
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                wf[a][k] = make_uint4(0, 0, 0, 0);
+                if (nt0 + a < ntiles && k < nk) wf[a][k] = wp[((size_t)(nt0 + a) * KT + kc + k) * 64 + lane];
+            }
+        __syncthreads();  // previous chunk's LDS reads are done
+        for (int f = wave; f < 2 * MT * KC; f += NW) {
+            const int plane = f / (MT * KC);
+            const int rem = f - plane * (MT * KC);
+            const int mt = rem / KC, k = rem - mt * KC;
+            const int row = m0 + mt * 16 + l15;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < M && k < nk) {
+                const uint16_t* src = (plane ? xl : xh) + (size_t)row * ldx + (size_t)(kc + k) * 32 + grp * 8;
+                v = *reinterpret_cast<const uint4*>(src);
+            }
+            lds[f * 64 + lane] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, lds[((0 * MT + b) * KC + k) * 64 + lane]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, lds[((1 * MT + b) * KC + k) * 64 + lane]);
+#pragma unroll
+                for (int a = 0; a < NT; ++a) {
+                    const bf16x8 w = __builtin_bit_cast(bf16x8, wf[a][k]);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, bh, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, bl, acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D[feature 4*grp+reg][token l15] -> out[token][feature..feature+3]
+    float* o = out + (size_t)blockIdx.y * (size_t)M * N;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        if (nt0 + a >= ntiles) continue;
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+            const int row = m0 + b * 16 + l15;
+            if (row < M) {
+                const f32x4 v = acc[a][b];
+                *reinterpret_cast<float4*>(o + (size_t)row * N + (size_t)(nt0 + a) * 16 + grp * 4) =
+                    make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+GemmPlan plan_gemm(int M, int N, int K, int max_split) {
+    GemmPlan p;
+    p.mt = M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 8;
+    p.kc = p.mt == 8 ? 4 : 8;
+    const int rowblocks = (M + 16 * p.mt - 1) / (16 * p.mt);
+    const int ntiles = N / 16;
+    p.nw = 4;
+    p.nt = ((int64_t)ntiles * rowblocks >= 2048) ? 2 : 1;
+    const int KT = K / 32;
+    const int64_t groups = (int64_t)((ntiles + p.nt * p.nw - 1) / (p.nt * p.nw)) * rowblocks;
+    int ns = 1;
+    while (groups * ns < 256 && ns * 2 <= max_split && KT / (ns * 2) >= 8) ns *= 2;
+    p.n_split = ns;
+    p.kt_per_split = (KT + ns - 1) / ns;
+    return p;
+}
+
+template <int MT, int NT, int NW, int KC>
+static hipError_t gemm_launch_t(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
+                                float* out, int M, hipStream_t s) {
+    const int ntiles = w.N / 16;
+    dim3 grid((ntiles + NT * NW - 1) / (NT * NW), p.n_split, (M + MT * 16 - 1) / (MT * 16));
+    const size_t lds = (size_t)2 * MT * KC * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<MT, NT, NW, KC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    gemm_kernel<MT, NT, NW, KC><<<grid, NW * 64, lds, s>>>(xh, xl, ldx, w.data, out, M, w.N, w.K / 32, p.kt_per_split);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
+                       float* out, int M, hipStream_t s) {
+#define NVLLM_GEMM_CASE(MT_, NT_, KC_) \
+    if (p.mt == MT_ && p.nt == NT_ && p.nw == 4 && p.kc == KC_) return gemm_launch_t<MT_, NT_, 4, KC_>(p, xh, xl, ldx, w, out, M, s);
+    NVLLM_GEMM_CASE(1, 1, 8)
+    NVLLM_GEMM_CASE(1, 2, 8)
+    NVLLM_GEMM_CASE(2, 1, 8)
+    NVLLM_GEMM_CASE(2, 2, 8)
+    NVLLM_GEMM_CASE(4, 1, 8)
+    NVLLM_GEMM_CASE(4, 2, 8)
+    NVLLM_GEMM_CASE(8, 1, 4)
+    NVLLM_GEMM_CASE(8, 2, 4)
+#undef NVLLM_GEMM_CASE
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// (embedding gather +) residual add + RMSNorm, one workgroup per row.
+// Replaces Tensor::embedding (qwen3.rs:465-468) and RMSNorm::forward (layernorm.rs:44-60):
+//   s = x (+ residual);  y = (s * (1/sqrt(mean(s^2)+eps))) * w;  new residual = s (stays f32).
+// x may arrive as n_slabs split-K partial sums of the producing GEMM (summed here).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kNormMaxV4 = 8;  // per-thread float4 cache: H <= 256*4*8 = 8192
+
+__global__ void __launch_bounds__(256) add_rmsnorm_kernel(NormArgs a) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const int src = a.row_idx ? a.row_idx[r] : r;
+    const int H = a.H, nv4 = H >> 2;
+    float4 cache[kNormMaxV4];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < kNormMaxV4; ++c) {
+        const int i = threadIdx.x + c * 256;
+        if (i < nv4) {
+            float4 s;
+            if (a.ids) {
+                const uint2 e = *reinterpret_cast<const uint2*>(a.embed + (size_t)a.ids[src] * H + (size_t)i * 4);
+                s = make_float4(bf16_to_f32(e.x & 0xffff), bf16_to_f32(e.x >> 16), bf16_to_f32(e.y & 0xffff),
+                                bf16_to_f32(e.y >> 16));
+            } else {
+                s = *reinterpret_cast<const float4*>(a.in + (size_t)src * H + (size_t)i * 4);
+                for (int sl = 1; sl < a.n_slabs; ++sl) {
+                    const float4 t =
+                        *reinterpret_cast<const float4*>(a.in + (size_t)sl * a.slab_stride + (size_t)src * H + (size_t)i * 4);
+                    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                }
+            }
+            if (a.residual_in) {
+                const float4 t = *reinterpret_cast<const float4*>(a.residual_in + (size_t)src * H + (size_t)i * 4);
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            if (a.residual_out) *reinterpret_cast<float4*>(a.residual_out + (size_t)src * H + (size_t)i * 4) = s;
+            cache[c] = s;
+            ss += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    const float rinv = 1.0f / sqrtf(ss / (float)H + a.eps);
+#pragma unroll
+    for (int c = 0; c < kNormMaxV4; ++c) {
+        const int i = threadIdx.x + c * 256;
+        if (i < nv4) {
+            const float4 s = cache[c];
+            const float4 w = *reinterpret_cast<const float4*>(a.weight + (size_t)i * 4);
+            const float y0 = (s.x * rinv) * w.x, y1 = (s.y * rinv) * w.y, y2 = (s.z * rinv) * w.z, y3 = (s.w * rinv) * w.w;
+            if (a.y) *reinterpret_cast<float4*>(a.y + (size_t)r * H + (size_t)i * 4) = make_float4(y0, y1, y2, y3);
+            if (a.xh) {
+                uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
+                split_bf16(y0, h0, l0); split_bf16(y1, h1, l1); split_bf16(y2, h2, l2); split_bf16(y3, h3, l3);
+                *reinterpret_cast<uint2*>(a.xh + (size_t)r * H + (size_t)i * 4) =
+                    make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
+                *reinterpret_cast<uint2*>(a.xl + (size_t)r * H + (size_t)i * 4) =
+                    make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
+            }
+        }
+    }
+}
+
+hipError_t launch_add_rmsnorm(const NormArgs& a, int rows, hipStream_t s) {
+    if (a.H % 4 != 0 || a.H > 256 * 4 * kNormMaxV4) return hipErrorInvalidValue;
+    if (rows <= 0) return hipSuccess;
+    add_rmsnorm_kernel<<<rows, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// q/k RMSNorm over head_dim + RoPE + KV-cache write; one wave per (row, head).
+// Replaces qwen3.rs:208-234 (narrow/reshape/transpose, q_norm/k_norm BEFORE RoPE and GQA expand) and
+// rotary_embedding.rs:82-107 (half-split: y1 = x1*cos - x2*sin, y2 = x2*cos + x1*sin).
+// K goes to the paged cache row-major f16; V goes in the PV A-fragment order:
+//   token tt (0..31) of a 32-token tile sits in k-slot (g, j): tt<16: g=tt>>2, j=tt&3; else g=(tt-16)>>2, j=4+(tt&3)
+//   element (tt, d) -> (((tile*(hd/16) + d/16)*64 + g*16 + d%16)*8 + j
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t v_packed_offset(int t_in_block, int d, int hd) {
+    const int tile = t_in_block >> 5, tt = t_in_block & 31;
+    const int g = (tt & 15) >> 2, j = ((tt >> 4) << 2) | (tt & 3);
+    return ((size_t)(tile * (hd >> 4) + (d >> 4)) * 64 + (g << 4) + (d & 15)) * 8 + j;
+}
+
+__global__ void __launch_bounds__(256) qk_norm_rope_kvwrite_kernel(QkvArgs a) {
+    const int row = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int hh = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int hd = a.kv.hd, half = hd >> 1, kv_l = a.kv.kv_l;
+    const int heads = a.nh_l + 2 * kv_l;
+    if (hh >= heads) return;
+    const int ldq = heads * hd;
+    const bool act = lane < half;
+    float x1 = 0.f, x2 = 0.f;
+    if (act) {
+        const float* p = a.qkv + (size_t)row * ldq + (size_t)hh * hd;
+        x1 = p[lane];
+        x2 = p[lane + half];
+        for (int sl = 1; sl < a.n_slabs; ++sl) {
+            x1 += p[(size_t)sl * a.slab_stride + lane];
+            x2 += p[(size_t)sl * a.slab_stride + lane + half];
+        }
+    }
+    const int pos = a.pos[row];
+    if (hh < a.nh_l + kv_l) {  // q or k head: norm + rope
+        const float* w = hh < a.nh_l ? a.qn : a.kn;
+        const float ss = wave_sum(x1 * x1 + x2 * x2);
+        const float rinv = 1.0f / sqrtf(ss / (float)hd + a.eps);
+        float y1 = 0.f, y2 = 0.f;
+        if (act) {
+            const float n1 = (x1 * rinv) * w[lane], n2 = (x2 * rinv) * w[lane + half];
+            const float c = a.cos[(size_t)pos * half + lane], s = a.sin[(size_t)pos * half + lane];
+            y1 = n1 * c - n2 * s;
+            y2 = n2 * c + n1 * s;
+        }
+        if (hh < a.nh_l) {
+            if (act) {
+                float* q = a.q_out + (size_t)row * (a.nh_l * hd) + (size_t)hh * hd;
+                q[lane] = y1 * a.q_scale;
+                q[lane + half] = y2 * a.q_scale;
+            }
+        } else if (act) {
+            const int kh = hh - a.nh_l;
+            const int blk = a.block_tables[(size_t)a.slot[row] * a.max_blocks + (pos >> 8)];
+            _Float16* k = reinterpret_cast<_Float16*>(a.kv.k) + ((size_t)(blk * kv_l + kh) * kBlockTokens + (pos & 255)) * hd;
+            k[lane] = f16_sat(y1);
+            k[lane + half] = f16_sat(y2);
+        }
+    } else if (act) {  // v head: plain copy into the packed layout
+        const int kh = hh - a.nh_l - kv_l;
+        const int blk = a.block_tables[(size_t)a.slot[row] * a.max_blocks + (pos >> 8)];
+        _Float16* v = reinterpret_cast<_Float16*>(a.kv.v) + (size_t)(blk * kv_l + kh) * kBlockTokens * hd;
+        v[v_packed_offset(pos & 255, lane, hd)] = f16_sat(x1);
+        v[v_packed_offset(pos & 255, lane + half, hd)] = f16_sat(x2);
+    }
+}
+
+hipError_t launch_qk_norm_rope_kvwrite(const QkvArgs& a, int rows, hipStream_t s) {
+    if (a.kv.hd > 128 || a.kv.hd % 32 != 0) return hipErrorInvalidValue;
+    if (rows <= 0) return hipSuccess;
+    const int heads = a.nh_l + 2 * a.kv.kv_l;
+    dim3 grid(rows, (heads + 3) / 4);
+    qk_norm_rope_kvwrite_kernel<<<grid, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+// plain K/V write (no norm / rope) for the fine-seam attention op
+__global__ void __launch_bounds__(256) kv_write_plain_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                             const int* __restrict__ pos, const int* __restrict__ slot,
+                                                             const int* __restrict__ bt, int max_blocks, KvLayout kv) {
+    const int row = blockIdx.x;
+    const int n = kv.kv_l * kv.hd;
+    const int p = pos[row];
+    const int blk = bt[(size_t)slot[row] * max_blocks + (p >> 8)];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int kh = i / kv.hd, d = i - kh * kv.hd;
+        _Float16* kd = reinterpret_cast<_Float16*>(kv.k) + ((size_t)(blk * kv.kv_l + kh) * kBlockTokens + (p & 255)) * kv.hd;
+        kd[d] = f16_sat(k[(size_t)row * n + i]);
+        _Float16* vd = reinterpret_cast<_Float16*>(kv.v) + (size_t)(blk * kv.kv_l + kh) * kBlockTokens * kv.hd;
+        vd[v_packed_offset(p & 255, d, kv.hd)] = f16_sat(v[(size_t)row * n + i]);
+    }
+}
+hipError_t launch_kv_write_plain(const float* k, const float* v, int rows, const int* pos, const int* slot,
+                                 const int* block_tables, int max_blocks, KvLayout kv, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    kv_write_plain_kernel<<<rows, 256, 0, s>>>(k, v, pos, slot, block_tables, max_blocks, kv);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Paged causal GQA attention (prefill q-tiles and decode rows through the same kernel).
+// Replaces qwen3.rs:236-277: GQA interleaved expand (q head h -> kv head h/(nh/kv)), scores*scale,
+// additive -1e9 mask for j>i (masked terms are exactly 0 after the f32 softmax, so they are skipped),
+// f32 softmax, p.v.  A KV cache is mathematically equivalent to the reference's full recompute (causal).
+//
+// One workgroup = one q-tile (QT sub-tiles of 16 MFMA rows = (16/gqa) tokens x gqa q-heads) x one kv head.
+// Its 4 waves take alternate 32-token KV tiles; K and V fragments go straight from HBM to VGPRs:
+//   S^T[token][qrow]  = K[token][:] . q[qrow][:]      A = K frag (16 rows x 64 B per wave-load), B = q (f16 hi+lo)
+//   O^T[dim][qrow]   += V^T[dim][token] . P[token][qrow]   A = V packed frag (1 KiB wave-load), B = P straight
+//                                                          from the S accumulators (no lane movement)
+// Both products keep the q row on lane&15, so the online-softmax state (m, l) is per-lane.
+// ---------------------------------------------------------------------------------------------------
+template <int HD, int QT>
+__global__ void __launch_bounds__(256) attn_paged_kernel(AttnArgs a) {
+    constexpr int DC = HD / 32, DT = HD / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* ml = reinterpret_cast<float*>(smem_raw);                        // [4][QT][2][16]
+    f32x4* obuf = reinterpret_cast<f32x4*>(smem_raw + 4 * QT * 2 * 16 * 4);  // [3][QT][DT][64]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int tile = blockIdx.x, kh = blockIdx.y;
+    const int row0 = a.tile_row0[tile], nrows = a.tile_nrows[tile], slot = a.tile_slot[tile];
+    const int gqa = a.gqa, tpq = 16 / gqa;
+    const int kv_l = a.kv.kv_l;
+    const int ldq = a.nh_l * HD;
+
+    int my_row[QT], my_pos[QT];
+    const int my_head = kh * gqa + (l15 % gqa);
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int tok = t * tpq + l15 / gqa;
+        const bool valid = (l15 < tpq * gqa) && (tok < nrows);
+        my_row[t] = valid ? row0 + tok : -1;
+        my_pos[t] = valid ? a.pos[row0 + tok] : -1;
+    }
+    const int pmax = a.pos[row0 + nrows - 1];
+    const int n_kv_tiles = (pmax >> 5) + 1;
+
+    f16x8 qh[QT][DC], ql[QT][DC];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            float x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (my_row[t] >= 0) {
+                const float4* p =
+                    reinterpret_cast<const float4*>(a.q + (size_t)my_row[t] * ldq + (size_t)my_head * HD + c * 32 + grp * 8);
+                const float4 u = p[0], w = p[1];
+                x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = w.x; x[5] = w.y; x[6] = w.z; x[7] = w.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 h = (_Float16)x[j];
+                qh[t][c][j] = h;
+                ql[t][c][j] = (_Float16)(x[j] - (float)h);
+            }
+        }
+
+    f32x4 o[QT][DT];
+    float m[QT], lsum[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m[t] = -1e30f;
+        lsum[t] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int* bt = a.block_tables + (size_t)slot * a.max_blocks;
+    const _Float16* kbase = reinterpret_cast<const _Float16*>(a.kv.k);
+    const _Float16* vbase = reinterpret_cast<const _Float16*>(a.kv.v);
+    for (int kt = wave; kt < n_kv_tiles; kt += 4) {
+        const int T0 = kt << 5;
+        const int blk = bt[T0 >> 8];
+        const int tb = T0 & 255;
+        const _Float16* kb = kbase + ((size_t)(blk * kv_l + kh) * kBlockTokens + tb) * HD + grp * 8;
+        uint4 ka[DC], kb2[DC];
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            ka[c] = *reinterpret_cast<const uint4*>(kb + (size_t)l15 * HD + c * 32);
+            kb2[c] = *reinterpret_cast<const uint4*>(kb + (size_t)(16 + l15) * HD + c * 32);
+        }
+        const _Float16* vb = vbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 5) * (DT * 512);
+        uint4 vf[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) vf[d] = *reinterpret_cast<const uint4*>(vb + d * 512 + lane * 8);
+
+        const int tokA = T0 + grp * 4, tokB = T0 + 16 + grp * 4;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < DC; ++c) {
+                const f16x8 fa = __builtin_bit_cast(f16x8, ka[c]);
+                const f16x8 fb = __builtin_bit_cast(f16x8, kb2[c]);
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, qh[t][c], sa, 0, 0, 0);
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, ql[t][c], sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, qh[t][c], sb, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, ql[t][c], sb, 0, 0, 0);
+            }
+            float mt = -1e30f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (tokA + r <= my_pos[t]) mt = fmaxf(mt, sa[r]);
+                if (tokB + r <= my_pos[t]) mt = fmaxf(mt, sb[r]);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 16));
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float mn = fmaxf(m[t], mt);
+            const float alpha = exp2f(m[t] - mn);
+            m[t] = mn;
+            f16x8 P;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pa = (tokA + r <= my_pos[t]) ? exp2f(sa[r] - mn) : 0.f;
+                const float pb = (tokB + r <= my_pos[t]) ? exp2f(sb[r] - mn) : 0.f;
+                ps += pa + pb;
+                P[r] = (_Float16)pa;
+                P[4 + r] = (_Float16)pb;
+            }
+            lsum[t] = lsum[t] * alpha + ps;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                f32x4 acc = o[t][d];
+                acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+                o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vf[d]), P, acc, 0, 0, 0);
+            }
+        }
+    }
+
+    // combine the 4 waves' partial (m, l, O)
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float l = lsum[t];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        lsum[t] = l;
+        if (grp == 0) {
+            ml[((wave * QT + t) * 2 + 0) * 16 + l15] = m[t];
+            ml[((wave * QT + t) * 2 + 1) * 16 + l15] = l;
+        }
+    }
+    __syncthreads();
+    float ltot[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float ms = -1e30f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) ms = fmaxf(ms, ml[((w * QT + t) * 2 + 0) * 16 + l15]);
+        float lt = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+            lt += ml[((w * QT + t) * 2 + 1) * 16 + l15] * exp2f(ml[((w * QT + t) * 2 + 0) * 16 + l15] - ms);
+        ltot[t] = lt;
+        const float f = exp2f(m[t] - ms);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            o[t][d][0] *= f; o[t][d][1] *= f; o[t][d][2] *= f; o[t][d][3] *= f;
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int d = 0; d < DT; ++d) obuf[(((wave - 1) * QT + t) * DT + d) * 64 + lane] = o[t][d];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            if (my_row[t] < 0) continue;
+            const float inv = 1.0f / ltot[t];
+            const size_t base = (size_t)my_row[t] * ldq + (size_t)my_head * HD + grp * 4;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                f32x4 acc = o[t][d];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const f32x4 v = obuf[((w * QT + t) * DT + d) * 64 + lane];
+                    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+                }
+                const float y0 = acc[0] * inv, y1 = acc[1] * inv, y2 = acc[2] * inv, y3 = acc[3] * inv;
+                if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + base + d * 16) = make_float4(y0, y1, y2, y3);
+                if (a.out_hi) {
+                    uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
+                    split_bf16(y0, h0, l0); split_bf16(y1, h1, l1); split_bf16(y2, h2, l2); split_bf16(y3, h3, l3);
+                    *reinterpret_cast<uint2*>(a.out_hi + base + d * 16) =
+                        make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
+                    *reinterpret_cast<uint2*>(a.out_lo + base + d * 16) =
+                        make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
+                }
+            }
+        }
+    }
+}
+
+template <int HD, int QT>
+static hipError_t attn_launch_t(const AttnArgs& a, int n_tiles, hipStream_t s) {
+    constexpr int DT = HD / 16;
+    const size_t lds = (size_t)4 * QT * 2 * 16 * 4 + (size_t)3 * QT * DT * 64 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_paged_kernel<HD, QT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid(n_tiles, a.kv.kv_l);
+    attn_paged_kernel<HD, QT><<<grid, 256, lds, s>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_paged(const AttnArgs& a, int n_tiles, int qt, hipStream_t s) {
+    if (n_tiles <= 0) return hipSuccess;
+    if (a.gqa < 1 || a.gqa > 16) return hipErrorInvalidValue;
+    if (a.kv.hd == 128 && qt == 1) return attn_launch_t<128, 1>(a, n_tiles, s);
+    if (a.kv.hd == 128 && qt == 2) return attn_launch_t<128, 2>(a, n_tiles, s);
+    if (a.kv.hd == 64 && qt == 1) return attn_launch_t<64, 1>(a, n_tiles, s);
+    if (a.kv.hd == 64 && qt == 2) return attn_launch_t<64, 2>(a, n_tiles, s);
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SwiGLU gate: SiluAndMul::forward (activation.rs:13-18): split last dim in two, silu(a)*b
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) silu_mul_kernel(const float* __restrict__ gu, int n_slabs, int64_t slab_stride,
+                                                       int rows, int I, uint16_t* __restrict__ hi,
+                                                       uint16_t* __restrict__ lo, float* __restrict__ y) {
+    const int64_t total = (int64_t)rows * (I >> 2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / (I >> 2));
+        const int c = (int)(i % (I >> 2)) * 4;
+        const float* pg = gu + (size_t)r * 2 * I + c;
+        float4 g = *reinterpret_cast<const float4*>(pg);
+        float4 u = *reinterpret_cast<const float4*>(pg + I);
+        for (int sl = 1; sl < n_slabs; ++sl) {
+            const float4 g2 = *reinterpret_cast<const float4*>(pg + (size_t)sl * slab_stride);
+            const float4 u2 = *reinterpret_cast<const float4*>(pg + (size_t)sl * slab_stride + I);
+            g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+            u.x += u2.x; u.y += u2.y; u.z += u2.z; u.w += u2.w;
+        }
+        const float y0 = (g.x / (1.0f + __expf(-g.x))) * u.x, y1 = (g.y / (1.0f + __expf(-g.y))) * u.y;
+        const float y2 = (g.z / (1.0f + __expf(-g.z))) * u.z, y3 = (g.w / (1.0f + __expf(-g.w))) * u.w;
+        if (y) *reinterpret_cast<float4*>(y + (size_t)r * I + c) = make_float4(y0, y1, y2, y3);
+        if (hi) {
+            uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
+            split_bf16(y0, h0, l0); split_bf16(y1, h1, l1); split_bf16(y2, h2, l2); split_bf16(y3, h3, l3);
+            *reinterpret_cast<uint2*>(hi + (size_t)r * I + c) = make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
+            *reinterpret_cast<uint2*>(lo + (size_t)r * I + c) = make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
+        }
+    }
+}
+hipError_t launch_silu_mul(const float* gu, int n_slabs, int64_t slab_stride, int rows, int I, bf16_bits* hi,
+                           bf16_bits* lo, float* y, hipStream_t s) {
+    if (I % 4 != 0) return hipErrorInvalidValue;
+    if (rows <= 0) return hipSuccess;
+    silu_mul_kernel<<<grid_for((int64_t)rows * (I / 4)), 256, 0, s>>>(gu, n_slabs, slab_stride, rows, I, hi, lo, y);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// misc
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) slab_sum_kernel(const float* __restrict__ in, int n_slabs, int64_t slab_stride,
+                                                       int64_t ld_in, const float* __restrict__ bias, int rows, int N,
+                                                       float* __restrict__ y, int64_t ld_out) {
+    const int64_t total = (int64_t)rows * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / N;
+        const int n = (int)(i - r * N);
+        float v = in[r * ld_in + n];
+        for (int sl = 1; sl < n_slabs; ++sl) v += in[(size_t)sl * slab_stride + r * ld_in + n];
+        if (bias) v += bias[n];
+        y[r * ld_out + n] = v;
+    }
+}
+hipError_t launch_slab_sum(const float* in, int n_slabs, int64_t slab_stride, const float* bias, int rows, int N,
+                           float* y, hipStream_t s) {
+    return launch_slab_sum_ld(in, n_slabs, slab_stride, N, bias, rows, N, y, N, s);
+}
+hipError_t launch_slab_sum_ld(const float* in, int n_slabs, int64_t slab_stride, int64_t ld_in, const float* bias,
+                              int rows, int N, float* y, int64_t ld_out, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    slab_sum_kernel<<<grid_for((int64_t)rows * N), 256, 0, s>>>(in, n_slabs, slab_stride, ld_in, bias, rows, N, y, ld_out);
+    return hipGetLastError();
+}
+
+// ---- generic-shape fallbacks for the fine-seam ops (any n; the step path never uses them) -------------
+__global__ void __launch_bounds__(256) rmsnorm_generic_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                              const float* __restrict__ w, float eps, int n,
+                                                              float* __restrict__ y, float* __restrict__ res_out) {
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * n;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float s = res ? x[base + i] + res[base + i] : x[base + i];
+        ss += s * s;
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    const float rinv = 1.0f / sqrtf(ss / (float)n + eps);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float s = res ? x[base + i] + res[base + i] : x[base + i];
+        if (res_out) res_out[base + i] = s;
+        y[base + i] = (s * rinv) * w[i];
+    }
+}
+hipError_t launch_rmsnorm_generic(const float* x, const float* res, const float* w, float eps, int rows, int n, float* y,
+                                  float* res_out, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    rmsnorm_generic_kernel<<<rows, 256, 0, s>>>(x, res, w, eps, n, y, res_out);
+    return hipGetLastError();
+}
+__global__ void __launch_bounds__(256) silu_mul_generic_kernel(const float* __restrict__ x, int64_t total, int n,
+                                                               float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n;
+        const int c = (int)(i - r * n);
+        const float g = x[r * 2 * n + c], u = x[r * 2 * n + n + c];
+        y[i] = (g / (1.0f + __expf(-g))) * u;
+    }
+}
+hipError_t launch_silu_mul_generic(const float* x, int rows, int n, float* y, hipStream_t s) {
+    const int64_t total = (int64_t)rows * n;
+    if (total <= 0) return hipSuccess;
+    silu_mul_generic_kernel<<<grid_for(total), 256, 0, s>>>(x, total, n, y);
+    return hipGetLastError();
+}
+// x f32 [rows][K] -> hi/lo bf16 [rows][Kpad] (zero beyond K)
+__global__ void __launch_bounds__(256) split_hilo_pad_kernel(const float* __restrict__ x, int K, int Kpad, int64_t total,
+                                                             uint16_t* __restrict__ hi, uint16_t* __restrict__ lo) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / Kpad;
+        const int c = (int)(i - r * Kpad);
+        uint16_t h = 0, l = 0;
+        if (c < K) split_bf16(x[r * K + c], h, l);
+        hi[i] = h;
+        lo[i] = l;
+    }
+}
+hipError_t launch_split_hilo_pad(const float* x, int rows, int K, int Kpad, bf16_bits* hi, bf16_bits* lo, hipStream_t s) {
+    const int64_t total = (int64_t)rows * Kpad;
+    if (total <= 0) return hipSuccess;
+    split_hilo_pad_kernel<<<grid_for(total), 256, 0, s>>>(x, K, Kpad, total, hi, lo);
+    return hipGetLastError();
+}
+
+// argmax, LAST maximal element wins (Iterator::max_by, llm_engine.rs:135-142; tests/layer_test.rs:144-149)
+__global__ void __launch_bounds__(1024) argmax_kernel(const float* __restrict__ logits, int V, int64_t ld,
+                                                      uint32_t* __restrict__ ids, float* __restrict__ maxval) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const float* p = logits + (size_t)blockIdx.x * ld;
+    float bv = -INFINITY;
+    int bi = -1;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        const float v = p[i];
+        if (v >= bv || bi < 0) { bv = v; bi = i; }  // i increases per thread: >= keeps the last
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+            if (si[w] >= 0 && (bi < 0 || sv[w] > bv || (sv[w] == bv && si[w] > bi))) { bv = sv[w]; bi = si[w]; }
+        ids[blockIdx.x] = (uint32_t)(bi < 0 ? 0 : bi);
+        if (maxval) maxval[blockIdx.x] = bv;
+    }
+}
+hipError_t launch_argmax(const float* logits, int rows, int V, int64_t ld, uint32_t* ids, float* maxval,
+                         hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    argmax_kernel<<<rows, 1024, 0, s>>>(logits, V, ld, ids, maxval);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) embedding_f32_kernel(const float* __restrict__ table,
+                                                            const uint32_t* __restrict__ ids, int V, int H,
+                                                            float* __restrict__ y) {
+    const uint32_t id = ids[blockIdx.x];
+    for (int i = threadIdx.x; i < H; i += blockDim.x)
+        y[(size_t)blockIdx.x * H + i] = id < (uint32_t)V ? table[(size_t)id * H + i] : 0.f;
+}
+hipError_t launch_embedding_f32(const float* table, const uint32_t* ids, int n, int V, int H, float* y,
+                                hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    embedding_f32_kernel<<<n, 256, 0, s>>>(table, ids, V, H, y);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) rope_bhtd_kernel(float* __restrict__ x, int T, int hd,
+                                                        const float* __restrict__ cosv, const float* __restrict__ sinv,
+                                                        int64_t total_pairs) {
+    const int half = hd >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_pairs; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % half);
+        const int64_t vec = i / half;  // (b*heads + h)*T + t
+        const int t = (int)(vec % T);
+        float* v = x + vec * hd;
+        const float c = cosv[(size_t)t * half + j], s = sinv[(size_t)t * half + j];
+        const float x1 = v[j], x2 = v[j + half];
+        v[j] = x1 * c - x2 * s;
+        v[j + half] = x2 * c + x1 * s;
+    }
+}
+hipError_t launch_rope_bhtd(float* x, int B, int heads, int T, int hd, const float* cos, const float* sin,
+                            hipStream_t s) {
+    const int64_t total = (int64_t)B * heads * T * (hd / 2);
+    if (total <= 0) return hipSuccess;
+    rope_bhtd_kernel<<<grid_for(total), 256, 0, s>>>(x, T, hd, cos, sin, total);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) bhtd_to_rows_kernel(const float* __restrict__ x, int B, int heads, int T, int hd,
+                                                           float scale, float* __restrict__ y) {
+    const int64_t total = (int64_t)B * heads * T * hd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % hd);
+        int64_t r = i / hd;
+        const int t = (int)(r % T); r /= T;
+        const int h = (int)(r % heads);
+        const int b = (int)(r / heads);
+        y[((size_t)(b * T + t) * heads + h) * hd + d] = x[i] * scale;
+    }
+}
+hipError_t launch_bhtd_to_rows(const float* x, int B, int heads, int T, int hd, float scale, float* y,
+                               hipStream_t s) {
+    const int64_t total = (int64_t)B * heads * T * hd;
+    if (total <= 0) return hipSuccess;
+    bhtd_to_rows_kernel<<<grid_for(total), 256, 0, s>>>(x, B, heads, T, hd, scale, y);
+    return hipGetLastError();
+}
+
+__global__ void advance_decode_kernel(uint32_t* ids, const uint32_t* next, int* pos, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { ids[i] = next[i]; pos[i] += 1; }
+}
+hipError_t launch_advance_decode(uint32_t* ids, const uint32_t* next, int* pos, int n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    advance_decode_kernel<<<(n + 255) / 256, 256, 0, s>>>(ids, next, pos, n);
+    return hipGetLastError();
+}
+
+}  // namespace nvllm
