@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- decode tokens/s of the MI355X-native Qwen3 forward path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--model qwen3-0.6b] [--batch 64]
+
+One "step" = one decode step of the whole batch through the HIP path (libnvllm_amd.so, C ABI):
+every live sequence gets one new token; the greedy ids come back to the host every step, as the
+reference's LLMEngine.step consumes them (src/engine/llm_engine.rs:239-264).
+
+N = 1  Qwen3-0.6B shapes, 64 live sequences (BASELINE.json configs[2] steady state: prompt lengths
+       uniform 64..512, seed 0), synthetic bf16 weights generated in HBM, prefill untimed.
+N > 1  the same workload tensor-parallel over N ranks (one process per GPU, RCCL all-reduce after
+       o_proj and down_proj, vocab-parallel LM head): total work fixed => "strong" scaling.
+
+Prints ONE JSON line on rank 0 (driver contract) with `roofline` (dominant kernel, HIP events on the
+library stream) and `cpu_baseline` (the C oracle in the reference's no-KV-cache mode on host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="qwen3-0.6b", choices=["qwen3-0.6b", "qwen3-8b", "qwen3-32b", "tiny"])
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--prompt-min", type=int, default=64)
+    ap.add_argument("--prompt-max", type=int, default=512)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seqs", type=int, default=2, help="sequences of the batch the CPU baseline re-runs")
+    ap.add_argument("--profile-steps", type=int, default=8, help="extra steps for the per-kernel HIP-event pass")
+    return ap.parse_args()
+
+
+def model_config(pkg, name):
+    return {"qwen3-0.6b": pkg.Qwen3Config.qwen3_0_6b, "qwen3-8b": pkg.Qwen3Config.qwen3_8b,
+            "qwen3-32b": pkg.Qwen3Config.qwen3_32b, "tiny": pkg.Qwen3Config.tiny}[name]()
+
+
+def make_prompts(cfg, batch, lo, hi, seed):
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(lo, hi + 1, size=batch)
+    return [rng.integers(0, cfg.vocab_size, size=int(n), dtype=np.uint32).tolist() for n in lens]
+
+
+def cpu_baseline(cfg, prompts, n_seqs, seed):
+    """The reference's CPU path restated (oracle/qwen3_oracle.c): no KV cache, whole sequences re-fed,
+    LM head on all rows -- one engine step for the first n_seqs sequences of the batch."""
+    from oracle import oracle as O
+
+    ocfg = O.make_config(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, head_dim=cfg.head_dim,
+                         num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                         num_key_value_heads=cfg.num_key_value_heads, intermediate_size=cfg.intermediate_size,
+                         max_position_embeddings=cfg.max_position_embeddings, rms_norm_eps=cfg.rms_norm_eps,
+                         rope_theta=cfg.rope_theta, bos_token_id=cfg.bos_token_id, eos_token_id=cfg.eos_token_id)
+    om = O.Model(ocfg).fill_synthetic(seed)
+    sample = [list(p) for p in prompts[:n_seqs]]
+    t0 = time.perf_counter()
+    om.run_greedy(sample, all_rows=True, want_logits=False)
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or len(os.sched_getaffinity(0))
+    return {"value": n_seqs / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"1 engine step of {n_seqs} of the {len(prompts)} sequences (lens {[len(s) for s in sample]}), "
+                      f"reference mode: no KV cache, full re-forward, LM head on all rows; {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import numpy as np
+    import torch
+
+    import nano_vllm_candle_amd as pkg
+
+    dist = None
+    rccl_id = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # control plane (id exchange, barrier, max over ranks) on gloo; the data path is RCCL inside the library
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        box = [pkg.Context.make_rccl_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        rccl_id = box[0]
+    torch.cuda.set_device(local_rank)
+    ctx = pkg.Context(local_rank, tp_rank=rank, tp_size=world, rccl_id=rccl_id)
+    cfg = model_config(pkg, a.model)
+    model = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=a.seed, ctx=ctx)
+    prompts = make_prompts(cfg, a.batch, a.prompt_min, a.prompt_max, a.seed)
+    total_steps = a.warmup + a.steps + a.profile_steps + 2
+    max_len = max(len(p) for p in prompts) + total_steps
+    blocks = sum(-(-(len(p) + total_steps) // 256) for p in prompts) + 2
+    model.kv_alloc(num_blocks=blocks, max_seqs=a.batch, max_batched_tokens=4096)
+    seq_ids = list(range(a.batch))
+
+    # prefill (untimed), in groups bounded like the reference scheduler's max_num_batched_tokens
+    model.step(seq_ids, prompts, is_prefill=True)
+    ctx_lens = np.array([len(p) + 1 for p in prompts], dtype=np.int64)  # tokens attended by the next decode step
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        model.decode_next()
+        ctx_lens += 1
+    barrier()
+    torch.cuda.synchronize()
+    bytes_total = 0
+    ctx.timer_start()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        model.decode_next()          # ids of all sequences come back to the host here
+        bytes_total += model.last_step_bytes
+        ctx_lens += 1
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    ev_ms = ctx.timer_stop()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt * 1e3 / a.steps
+    tok_s = a.batch * a.steps / dt
+    mean_ctx = float(ctx_lens.mean()) - a.steps / 2
+
+    # per-kernel HIP-event pass (outside the timed region; same process, same resident state)
+    kern = {}
+    pass_steps = max(1, a.profile_steps // 4)
+    attn_ctx = []
+    for kind in ("attn", "gemm", "lm_head", "norm", "qk", "silu"):
+        model.profile_kernel(kind)
+        for _ in range(pass_steps):
+            if kind == "attn":
+                attn_ctx.append(int(ctx_lens.sum()))
+            model.decode_next()
+            ctx_lens += 1
+        kern[kind] = model.profile_read()
+    model.profile_kernel(None)
+    per_step = {k: ms / pass_steps for k, (ms, n) in kern.items()}
+    dom = max(per_step, key=per_step.get)
+    dom_ms, dom_n = kern[dom]
+    kv_layer = model.kv_bytes_per_token // cfg.num_hidden_layers  # K+V bytes of one token in one layer (this rank)
+    if dom == "attn":
+        # algorithmic bytes of one launch = every attended token's K and V of this layer, read once
+        dom_bytes = float(np.mean(attn_ctx)) * kv_layer
+        dom_name = "attn_paged_kernel<128,1>"
+    elif dom == "lm_head":
+        dom_bytes = float(cfg.hidden_size * (cfg.vocab_size // world) * 2)
+        dom_name = "gemm_kernel (LM head)"
+    elif dom == "gemm":
+        dom_bytes = float(model.weight_bytes - cfg.hidden_size * (cfg.vocab_size // world) * 2) / (4 * cfg.num_hidden_layers)
+        dom_name = "gemm_kernel (layer projections, mean of qkv/o/gate_up/down)"
+    else:
+        dom_bytes = None
+        dom_name = dom
+    step_gbs = (bytes_total / a.steps) / (ev_ms / a.steps * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": dom_name, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+            "avg_launch_us": dom_ms / max(dom_n, 1) * 1e3}
+    if dom_bytes is not None:
+        roof["achieved"] = dom_bytes / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        roof["bytes_per_launch"] = dom_bytes
+    out = {
+        "metric": "decode tokens/sec", "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "dtype": "bf16 weights, f16 KV cache, bf16x2(hi+lo)/f16 MFMA operands, f32 accumulate",
+        "data": "synthetic",
+        "config": {"workload": f"{a.model} decode, {a.batch} live sequences, prompts U[{a.prompt_min},{a.prompt_max}] seed {a.seed}",
+                   "batch": a.batch, "mean_context": round(mean_ctx, 1), "parallelism": f"tp{world}"},
+        "roofline": roof,
+        "step_roofline": {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": step_gbs / HBM_PEAK_GBS, "bytes_per_step": bytes_total / a.steps,
+                          "event_ms_per_step": ev_ms / a.steps},
+        "kernel_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
+    }
+    if rank == 0 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, prompts, a.cpu_seqs, a.seed)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,7 +8,7 @@
  *   coarse seam  trait ModelRunner { fn run(&mut self, seqs, is_prefill) -> Vec<usize> }
  *                (src/engine/llm_engine.rs:16-18, impl :145-189)          -> nvllm_step()
  *   fine seam    layers::{RMSNorm, RotaryEmbedding, SiluAndMul, *ParallelLinear, Attention}
- *                (src/layers/*.rs) and tp::TPConfig (src/tp.rs)            -> nvllm_op_*()
+ *                (src/layers/) and tp::TPConfig (src/tp.rs)            -> nvllm_op_*()
  *
  * Conventions: plain C; opaque handles; every function returns 0 on success, a negative
  * NVLLM_E* code otherwise and records a message for nvllm_last_error(); no exceptions cross
@@ -95,6 +95,12 @@ int nvllm_model_finalize(nvllm_model* m);
 /* bytes of weights this rank reads per decode step (layers + final norm + LM head; embedding excluded) */
 int64_t nvllm_model_weight_bytes(const nvllm_model* m);
 
+/* Host-only helper (no GPU): the region {row0, col0, rows, cols} of the FULL HF tensor that rank tp_rank of
+ * tp_size owns -- column-parallel q/k/v/gate/up/lm_head shard rows, row-parallel o/down shard columns, norms and
+ * the embedding are replicated.  This is the working version of the reference's shard arithmetic
+ * (src/tp.rs:59-65; src/layers/linear.rs:80-89,201-210 only work for rank 0). */
+int nvllm_tp_shard(const nvllm_qwen3_config* cfg, int tp_size, int tp_rank, const char* hf_name, int64_t out_region[4]);
+
 /* ---- KV block pool (the real allocation the reference's stub BlockManager lacks,
  *      src/engine/block_manager.rs:24-29,64-98).  block_size must be 256 (src/engine/sequence.rs:35).
  *      max_batched_tokens bounds the rows processed per internal chunk (prefill is chunked). */
@@ -126,6 +132,12 @@ int nvllm_decode_next(nvllm_model* m, uint32_t* next_ids);
 /* per-decode-step algorithmic HBM bytes of the LAST step on this rank:
  * weight_bytes + sum_seq ctx*kv_tok + n_seqs*kv_tok (+ 4*n_seqs*vocab when logits left the device) */
 int64_t nvllm_last_step_bytes(const nvllm_model* m);
+/* HIP-event timing of one kernel class on the library stream (bench.py's roofline leg):
+ * kind 0 off, 1 paged attention, 2 layer GEMMs, 3 add+RMSNorm, 4 qk-norm/RoPE/KV-write, 5 SwiGLU, 6 LM head.
+ * While a kind is set every launch of that class is bracketed by two events; read returns the summed
+ * elapsed ms and the number of launches since the last read. */
+int nvllm_profile_kernel(nvllm_model* m, int kind);
+int nvllm_profile_read(nvllm_model* m, double* total_ms, int64_t* launches);
 /* copy per-layer taps of the last step to the host (debug/parity): what = 0 layer output h,
  * 1 residual; [rows, hidden] f32 of layer `layer`; rows = rows of the last step's last chunk */
 int nvllm_debug_layer_tap(nvllm_model* m, int layer, int what, float* out, int64_t capacity_floats);
@@ -174,6 +186,16 @@ int nvllm_op_allreduce(nvllm_ctx* ctx, float* buf, int64_t count);
  * into a HOST buffer (generated on the GPU, copied back) */
 int nvllm_op_synth_bf16(nvllm_ctx* ctx, const char* name, uint64_t seed, int kind, int64_t first, int64_t count,
                         uint16_t* host_out);
+
+/* tuning aid: time one decomposition (n-tiles per wave, waves per workgroup, K splits; 0 = planner's choice)
+ * of y[M,N] = x[M,K].W^T on synthetic operands; returns microseconds per launch */
+int nvllm_debug_gemm_bench(nvllm_ctx* ctx, int M, int N, int K, int nt, int nw, int n_split, int iters,
+                           float* us_per_call);
+
+/* tuning aid: time the decode attention (one new token per sequence, ctx_lens[B] cached tokens each) on a
+ * synthetic cache; part_tokens > 0 splits every context into workgroups of that many tokens */
+int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int hd, const int32_t* ctx_lens, int part_tokens,
+                           int iters, float* us_per_call);
 
 /* device memory helpers so a non-HIP host (Rust, ctypes) can feed the nvllm_op_* calls */
 int nvllm_dev_alloc(nvllm_ctx* ctx, size_t bytes, void** out);

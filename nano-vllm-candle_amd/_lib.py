@@ -54,6 +54,7 @@ _SIGS = {
     "nvllm_model_fill_synthetic": (C.c_int, [_vp, C.c_uint64]),
     "nvllm_model_finalize": (C.c_int, [_vp]),
     "nvllm_model_weight_bytes": (C.c_int64, [_vp]),
+    "nvllm_tp_shard": (C.c_int, [C.POINTER(Qwen3ConfigC), C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int64)]),
     "nvllm_kv_alloc": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "nvllm_kv_num_free_blocks": (C.c_int, [_vp]),
     "nvllm_kv_bytes_per_token": (C.c_int64, [_vp]),
@@ -62,6 +63,8 @@ _SIGS = {
                              C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "nvllm_decode_next": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "nvllm_last_step_bytes": (C.c_int64, [_vp]),
+    "nvllm_profile_kernel": (C.c_int, [_vp, C.c_int]),
+    "nvllm_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "nvllm_debug_layer_tap": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int64]),
     "nvllm_debug_enable_taps": (C.c_int, [_vp, C.c_int]),
     "nvllm_op_pack_weight": (C.c_int, [_vp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
@@ -75,6 +78,8 @@ _SIGS = {
     "nvllm_op_argmax": (C.c_int, [_vp, _fp, C.c_int, C.c_int, _fp]),
     "nvllm_op_allreduce": (C.c_int, [_vp, _fp, C.c_int64]),
     "nvllm_op_synth_bf16": (C.c_int, [_vp, C.c_char_p, C.c_uint64, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_uint16)]),
+    "nvllm_debug_gemm_bench": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "nvllm_debug_attn_bench": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "nvllm_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "nvllm_dev_free": (C.c_int, [_vp, _vp]),
     "nvllm_dev_upload": (C.c_int, [_vp, _vp, C.c_void_p, C.c_size_t]),

@@ -167,6 +167,8 @@ static int dmalloc(nvllm_ctx* c, T** p, size_t count) {
 // ---------------------------------------------------------------------------------------------------
 // model
 // ---------------------------------------------------------------------------------------------------
+constexpr int kAttnMaxParts = 64;  // split-KV partitions per sequence (partition grows with context beyond 8K)
+
 struct LayerW {
     PackedW qkv, o, gu, down;
     float *ln1 = nullptr, *ln2 = nullptr, *qn = nullptr, *kn = nullptr;
@@ -206,6 +208,12 @@ struct nvllm_model {
     float *resid = nullptr, *slabs = nullptr, *qbuf = nullptr, *logits = nullptr, *d_maxval = nullptr, *red = nullptr;
     bf16_bits *xh = nullptr, *xl = nullptr;
     uint32_t* d_next = nullptr;
+    float *attn_po = nullptr, *attn_pml = nullptr;  // split-KV partials [max_seqs][nh_l][kAttnMaxParts][hd] / [..][2]
+    int attn_part_tiles = 4, attn_parts_max = 1;   // this step's split geometry (decode only)
+    float* part_val = nullptr;  // fused LM-head arg-max partials [V_l/16][max_seqs]
+    int* part_idx = nullptr;
+    bool want_logits = false;   // this step stores the last-row logits
+    int cur_n = 0;              // sequences of the step in flight
     size_t slab_floats = 0;
     void* h_stage = nullptr;  // pinned
     size_t h_stage_bytes = 0;
@@ -218,7 +226,34 @@ struct nvllm_model {
     std::vector<int> last_lens;
     int64_t last_bytes = 0;
     bool decode_resident = false;  // device metadata describes a pure-decode batch == last_ids
+
+    // per-kernel-class HIP-event timing (bench roofline leg); 0 = off
+    int prof_kind = 0;
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_used = 0;
 };
+
+enum { PROF_ATTN = 1, PROF_GEMM = 2, PROF_NORM = 3, PROF_QK = 4, PROF_SILU = 5, PROF_LMHEAD = 6 };
+
+// bracket one launch with HIP events on the library stream when its class is being profiled
+#define PROF(m_, kind_, expr_)                                                           \
+    do {                                                                                  \
+        if ((m_)->prof_kind == (kind_)) {                                                 \
+            if ((m_)->prof_used + 2 > (m_)->prof_ev.size()) {                             \
+                for (int i_ = 0; i_ < 256; ++i_) {                                        \
+                    hipEvent_t evn_;                                                      \
+                    HIPCHK((m_)->ctx, hipEventCreate(&evn_));                              \
+                    (m_)->prof_ev.push_back(evn_);                                        \
+                }                                                                         \
+            }                                                                             \
+            HIPCHK((m_)->ctx, hipEventRecord((m_)->prof_ev[(m_)->prof_used], (m_)->ctx->stream));     \
+            HIPCHK((m_)->ctx, expr_);                                                     \
+            HIPCHK((m_)->ctx, hipEventRecord((m_)->prof_ev[(m_)->prof_used + 1], (m_)->ctx->stream)); \
+            (m_)->prof_used += 2;                                                         \
+        } else {                                                                          \
+            HIPCHK((m_)->ctx, expr_);                                                     \
+        }                                                                                 \
+    } while (0)
 
 static int model_fail(nvllm_model* m, int code, const char* fmt, ...) {
     char buf[1024];
@@ -247,8 +282,9 @@ extern "C" int nvllm_model_create(nvllm_ctx* ctx, const nvllm_qwen3_config* cfg,
     if (c.num_attention_heads / c.num_key_value_heads > 16) return fail(ctx, NVLLM_EINVAL, "GQA group > 16 unsupported");
     if (c.num_key_value_heads % tp || c.num_attention_heads % tp)
         return fail(ctx, NVLLM_EINVAL, "heads (%d q / %d kv) not divisible by tp_size %d", c.num_attention_heads, c.num_key_value_heads, tp);
-    if (c.hidden_size % 32 || c.hidden_size > 8192) return fail(ctx, NVLLM_EINVAL, "hidden_size must be a multiple of 32 and <= 8192");
-    if (c.intermediate_size % (32 * tp)) return fail(ctx, NVLLM_EINVAL, "intermediate_size must be a multiple of 32*tp");
+    if (c.hidden_size % 128 || c.hidden_size > 8192) return fail(ctx, NVLLM_EINVAL, "hidden_size must be a multiple of 128 and <= 8192");
+    if ((c.num_attention_heads / tp * c.head_dim) % 128) return fail(ctx, NVLLM_EINVAL, "per-rank q width (heads/tp * head_dim) must be a multiple of 128");
+    if (c.intermediate_size % (128 * tp)) return fail(ctx, NVLLM_EINVAL, "intermediate_size must be a multiple of 128*tp");
     if (c.vocab_size % (16 * tp)) return fail(ctx, NVLLM_EINVAL, "vocab_size must be a multiple of 16*tp");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     nvllm_model* m = new nvllm_model();
@@ -290,10 +326,10 @@ static void free_kv(nvllm_model* m) {
     m->kcache.clear(); m->vcache.clear();
     void* ptrs[] = {m->d_block_tables, m->d_ids, m->d_pos, m->d_slot, m->d_tile_row0, m->d_tile_nrows, m->d_tile_slot,
                     m->d_last_rows, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->d_next,
-                    m->tap_h, m->tap_res, m->cosv, m->sinv};
+                    m->part_val, m->part_idx, m->attn_po, m->attn_pml, m->tap_h, m->tap_res, m->cosv, m->sinv};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     m->d_block_tables = nullptr; m->d_ids = nullptr; m->d_pos = m->d_slot = m->d_tile_row0 = m->d_tile_nrows = m->d_tile_slot = m->d_last_rows = nullptr;
-    m->resid = m->slabs = m->qbuf = m->logits = m->d_maxval = m->red = nullptr; m->xh = m->xl = nullptr; m->d_next = nullptr;
+    m->resid = m->slabs = m->qbuf = m->logits = m->d_maxval = m->red = nullptr; m->xh = m->xl = nullptr; m->d_next = nullptr; m->part_val = nullptr; m->part_idx = nullptr; m->attn_po = m->attn_pml = nullptr;
     m->tap_h = m->tap_res = nullptr; m->cosv = m->sinv = nullptr;
     if (m->h_stage) (void)hipHostFree(m->h_stage);
     m->h_stage = nullptr;
@@ -305,6 +341,7 @@ extern "C" int nvllm_model_destroy(nvllm_model* m) {
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     free_kv(m);
+    for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     (void)hipFree(m->embed); (void)hipFree(m->lm_head.data); (void)hipFree(m->norm);
     for (auto& w : m->layers) {
         (void)hipFree(w.qkv.data); (void)hipFree(w.o.data); (void)hipFree(w.gu.data); (void)hipFree(w.down.data);
@@ -429,6 +466,30 @@ static int synth_one(nvllm_model* m, const char* name, uint64_t seed) {
     return NVLLM_OK;
 }
 
+// Host-only: which region of the FULL HF tensor `hf_name` rank `tp_rank` of `tp_size` owns
+// (row0, col0, rows, cols).  Same table nvllm_model_load_tensor / fill_synthetic use; no GPU needed.
+extern "C" int nvllm_tp_shard(const nvllm_qwen3_config* cfg, int tp_size, int tp_rank, const char* hf_name,
+                              int64_t out_region[4]) {
+    if (!cfg || !hf_name || !out_region || tp_size < 1 || tp_rank < 0 || tp_rank >= tp_size) return NVLLM_EINVAL;
+    if (cfg->num_attention_heads % tp_size || cfg->num_key_value_heads % tp_size || cfg->intermediate_size % tp_size ||
+        cfg->vocab_size % tp_size)
+        return NVLLM_EINVAL;
+    nvllm_ctx fake_ctx;
+    fake_ctx.tp_rank = tp_rank;
+    fake_ctx.tp_size = tp_size;
+    nvllm_model fake;
+    fake.ctx = &fake_ctx;
+    fake.cfg = *cfg;
+    fake.H = cfg->hidden_size; fake.hd = cfg->head_dim; fake.L = cfg->num_hidden_layers;
+    fake.nh_l = cfg->num_attention_heads / tp_size; fake.kv_l = cfg->num_key_value_heads / tp_size;
+    fake.I_l = cfg->intermediate_size / tp_size; fake.V_l = cfg->vocab_size / tp_size;
+    fake.layers.resize(fake.L);
+    Target t;
+    if (!resolve(&fake, hf_name, t)) return NVLLM_EINVAL;
+    out_region[0] = t.r0; out_region[1] = t.c0; out_region[2] = t.rows; out_region[3] = t.cols;
+    return NVLLM_OK;
+}
+
 extern "C" int nvllm_model_fill_synthetic(nvllm_model* m, uint64_t seed) {
     if (!m) return NVLLM_EINVAL;
     HIPCHK(m->ctx, hipSetDevice(m->ctx->device));
@@ -530,6 +591,10 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->xh, R * wide);
     if (!rc) rc = dmalloc(ctx, &m->xl, R * wide);
     if (!rc) rc = dmalloc(ctx, &m->d_next, (size_t)max_seqs * (ctx->tp_size + 1));
+    if (!rc) rc = dmalloc(ctx, &m->attn_po, (size_t)max_seqs * m->nh_l * kAttnMaxParts * m->hd);
+    if (!rc) rc = dmalloc(ctx, &m->attn_pml, (size_t)max_seqs * m->nh_l * kAttnMaxParts * 2);
+    if (!rc) rc = dmalloc(ctx, &m->part_val, (size_t)(m->V_l / 16) * max_seqs);
+    if (!rc) rc = dmalloc(ctx, &m->part_idx, (size_t)(m->V_l / 16) * max_seqs);
     if (rc) return rc;
     m->h_stage_bytes = (R * 6 + (size_t)max_seqs * 4) * sizeof(int) + 256;
     HIPCHK(ctx, hipHostMalloc(&m->h_stage, m->h_stage_bytes, hipHostMallocDefault));
@@ -635,10 +700,10 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         } else {       // qwen3.rs:378
             na.in = prev; na.n_slabs = prev_ns; na.slab_stride = (int64_t)R * H; na.residual_in = m->resid;
         }
-        HIPCHK(ctx, launch_add_rmsnorm(na, R, s));
+        PROF(m, PROF_NORM, launch_add_rmsnorm(na, R, s));
         // QKV projection (qwen3.rs:205)
         GemmPlan pq = plan_gemm(R, NQ, H, 8);
-        HIPCHK(ctx, launch_gemm(pq, m->xh, m->xl, H, w.qkv, m->slabs, R, s));
+        PROF(m, PROF_GEMM, launch_gemm(pq, m->xh, m->xl, H, w.qkv, m->slabs, R, s));
         QkvArgs qa;
         qa.qkv = m->slabs; qa.n_slabs = pq.n_split; qa.slab_stride = (int64_t)R * NQ; qa.qn = w.qn; qa.kn = w.kn; qa.eps = eps;
         qa.cos = m->cosv; qa.sin = m->sinv; qa.pos = m->d_pos; qa.slot = m->d_slot; qa.block_tables = m->d_block_tables;
@@ -646,29 +711,34 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         qa.q_scale = powf((float)hd, -0.5f) * 1.4426950408889634f;  // head_dim^-0.5 (qwen3.rs:134) * log2(e)
         qa.q_out = m->qbuf;
         qa.kv.k = m->kcache[l]; qa.kv.v = m->vcache[l]; qa.kv.kv_l = m->kv_l; qa.kv.hd = hd;
-        HIPCHK(ctx, launch_qk_norm_rope_kvwrite(qa, R, s));
+        PROF(m, PROF_QK, launch_qk_norm_rope_kvwrite(qa, R, s));
         AttnArgs aa;
         aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
         aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
         aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->xh; aa.out_lo = m->xl;
-        HIPCHK(ctx, launch_attn_paged(aa, n_tiles, qt, s));
+        int parts_max = 1;
+        if (qt == 1 && R <= m->max_seqs) {  // decode rows: split the context over workgroups
+            aa.part_tiles = m->attn_part_tiles; aa.max_parts = kAttnMaxParts; aa.part_o = m->attn_po; aa.part_ml = m->attn_pml;
+            parts_max = m->attn_parts_max;
+        }
+        PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
         // output projection (qwen3.rs:278) + TP all-reduce
         const int KO = m->nh_l * hd;
         GemmPlan po = plan_gemm(R, H, KO, 8);
-        HIPCHK(ctx, launch_gemm(po, m->xh, m->xl, KO, w.o, m->slabs, R, s));
+        PROF(m, PROF_GEMM, launch_gemm(po, m->xh, m->xl, KO, w.o, m->slabs, R, s));
         const float* oin; int ons;
         int rc = tp_reduce(m, R, po.n_split, &oin, &ons);
         if (rc) return rc;
         NormArgs nb;  // post-attention add + norm (qwen3.rs:393)
         nb.in = oin; nb.n_slabs = ons; nb.slab_stride = (int64_t)R * H; nb.residual_in = m->resid; nb.residual_out = m->resid;
         nb.weight = w.ln2; nb.eps = eps; nb.H = H; nb.xh = m->xh; nb.xl = m->xl;
-        HIPCHK(ctx, launch_add_rmsnorm(nb, R, s));
+        PROF(m, PROF_NORM, launch_add_rmsnorm(nb, R, s));
         // MLP (qwen3.rs:323-327)
         GemmPlan pg = plan_gemm(R, 2 * m->I_l, H, 8);
-        HIPCHK(ctx, launch_gemm(pg, m->xh, m->xl, H, w.gu, m->slabs, R, s));
-        HIPCHK(ctx, launch_silu_mul(m->slabs, pg.n_split, (int64_t)R * 2 * m->I_l, R, m->I_l, m->xh, m->xl, nullptr, s));
+        PROF(m, PROF_GEMM, launch_gemm(pg, m->xh, m->xl, H, w.gu, m->slabs, R, s));
+        PROF(m, PROF_SILU, launch_silu_mul(m->slabs, pg.n_split, (int64_t)R * 2 * m->I_l, R, m->I_l, m->xh, m->xl, nullptr, s));
         GemmPlan pd = plan_gemm(R, H, m->I_l, 8);
-        HIPCHK(ctx, launch_gemm(pd, m->xh, m->xl, m->I_l, w.down, m->slabs, R, s));
+        PROF(m, PROF_GEMM, launch_gemm(pd, m->xh, m->xl, m->I_l, w.down, m->slabs, R, s));
         rc = tp_reduce(m, R, pd.n_split, &prev, &prev_ns);
         if (rc) return rc;
         if (m->taps) {
@@ -684,8 +754,14 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         nf.weight = m->norm; nf.eps = eps; nf.H = H; nf.xh = m->xh; nf.xl = m->xl;
         HIPCHK(ctx, launch_add_rmsnorm(nf, n_last, s));
         GemmPlan pl = plan_gemm(n_last, m->V_l, H, 1);
-        float* lg = m->logits + (size_t)logits_row0 * m->V_l;  // TP: local shard rows, gathered later
-        HIPCHK(ctx, launch_gemm(pl, m->xh, m->xl, H, m->lm_head, lg, n_last, s));
+        // logits are stored only when the caller asked for them; the greedy id always comes from the
+        // GEMM epilogue's per-wave partial arg-max (LAST max wins), finished by one small kernel
+        float* lg = m->want_logits ? m->logits + (size_t)logits_row0 * m->V_l : nullptr;
+        PROF(m, PROF_LMHEAD, launch_gemm_argmax(pl, m->xh, m->xl, H, m->lm_head, lg, n_last, m->part_val, m->part_idx, s));
+        const int tp = ctx->tp_size;
+        uint32_t* ids_dst = tp == 1 ? m->d_next + logits_row0 : m->d_next + m->cur_n + (size_t)ctx->tp_rank * m->cur_n + logits_row0;
+        float* val_dst = tp == 1 ? nullptr : m->d_maxval + (size_t)ctx->tp_rank * m->cur_n + logits_row0;
+        HIPCHK(ctx, launch_argmax_parts(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, ids_dst, val_dst, s));
     }
     return NVLLM_OK;
 }
@@ -708,13 +784,23 @@ static int ensure_blocks(nvllm_model* m, SeqState& s, int len) {
     return NVLLM_OK;
 }
 
+// Split a sequence's context over several workgroups only when (sequences x kv heads) alone cannot fill
+// the chip (small batches, long contexts); a full batch already has >= 2 workgroups per CU.
+static void set_attn_split(nvllm_model* m, int n_seqs, int max_len) {
+    const int tiles = (max_len + 31) / 32;
+    const int base_wgs = std::max(1, n_seqs * m->kv_l);
+    int want = std::min(kAttnMaxParts, std::max(1, 512 / base_wgs));
+    int part = std::max(4, (tiles + want - 1) / want);  // >= 128 tokens per workgroup
+    m->attn_part_tiles = part;
+    m->attn_parts_max = (tiles + part - 1) / part;
+}
+
 // greedy ids (and optionally logits) of `n` last rows to the host; handles the vocab-parallel case
 static int finish_logits(nvllm_model* m, int n, uint32_t* next_ids, float* last_logits) {
     nvllm_ctx* ctx = m->ctx;
     hipStream_t s = ctx->stream;
     const int tp = ctx->tp_size, V = m->cfg.vocab_size, Vl = m->V_l;
     if (tp == 1) {
-        HIPCHK(ctx, launch_argmax(m->logits, n, V, V, m->d_next, nullptr, s));
         if (next_ids) HIPCHK(ctx, hipMemcpyAsync(next_ids, m->d_next, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         if (last_logits) HIPCHK(ctx, hipMemcpyAsync(last_logits, m->logits, (size_t)n * V * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
@@ -723,7 +809,6 @@ static int finish_logits(nvllm_model* m, int n, uint32_t* next_ids, float* last_
     // local (max, idx) -> all-gather -> pick the best; ties go to the higher global index
     uint32_t* idx_all = m->d_next + n;           // [tp][n] lives after the first n entries
     float* val_all = m->d_maxval;                // [tp][n]
-    HIPCHK(ctx, launch_argmax(m->logits, n, Vl, Vl, idx_all + (size_t)ctx->tp_rank * n, val_all + (size_t)ctx->tp_rank * n, s));
     NCCLCHK(ctx, ncclAllGather(idx_all + (size_t)ctx->tp_rank * n, idx_all, n, ncclUint32, ctx->comm, s));
     NCCLCHK(ctx, ncclAllGather(val_all + (size_t)ctx->tp_rank * n, val_all, n, ncclFloat, ctx->comm, s));
     std::vector<uint32_t> hi((size_t)tp * n);
@@ -831,6 +916,9 @@ extern "C" int nvllm_step(nvllm_model* m, int n_seqs, const int64_t* seq_ids, co
         if (rc) return rc;
     }
     HIPCHK(ctx, hipMemcpyAsync(m->d_block_tables, m->h_block_tables.data(), m->h_block_tables.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    m->want_logits = last_logits != nullptr;
+    m->cur_n = n_seqs;
+    set_attn_split(m, n_seqs, *std::max_element(lens, lens + n_seqs));
     // rows and q-tiles
     RowPlan p;
     bool all_single = true;
@@ -920,6 +1008,9 @@ extern "C" int nvllm_decode_next(nvllm_model* m, uint32_t* next_ids) {
         HIPCHK(ctx, hipMemcpyAsync(m->d_ids, m->d_next, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
         m->decode_resident = true;
     }
+    m->want_logits = false;
+    m->cur_n = n;
+    set_attn_split(m, n, *std::max_element(m->last_lens.begin(), m->last_lens.end()) + 1);
     int rc = forward_chunk(m, n, n, 1, n, 0);
     if (rc) return rc;
     rc = finish_logits(m, n, next_ids, nullptr);
@@ -935,6 +1026,28 @@ extern "C" int nvllm_decode_next(nvllm_model* m, uint32_t* next_ids) {
 }
 
 extern "C" int64_t nvllm_last_step_bytes(const nvllm_model* m) { return m ? m->last_bytes : 0; }
+
+extern "C" int nvllm_profile_kernel(nvllm_model* m, int kind) {
+    if (!m || kind < 0 || kind > PROF_LMHEAD) return NVLLM_EINVAL;
+    HIPCHK(m->ctx, hipStreamSynchronize(m->ctx->stream));
+    m->prof_kind = kind;
+    m->prof_used = 0;
+    return NVLLM_OK;
+}
+extern "C" int nvllm_profile_read(nvllm_model* m, double* total_ms, int64_t* launches) {
+    if (!m || !total_ms || !launches) return NVLLM_EINVAL;
+    HIPCHK(m->ctx, hipStreamSynchronize(m->ctx->stream));
+    double t = 0;
+    for (size_t i = 0; i + 1 < m->prof_used; i += 2) {
+        float ms = 0;
+        HIPCHK(m->ctx, hipEventElapsedTime(&ms, m->prof_ev[i], m->prof_ev[i + 1]));
+        t += ms;
+    }
+    *total_ms = t;
+    *launches = (int64_t)(m->prof_used / 2);
+    m->prof_used = 0;
+    return NVLLM_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // fine seam: single ops on raw device pointers (layer-level parity tests; src/layers/*.rs surface)
@@ -960,7 +1073,7 @@ extern "C" int nvllm_op_pack_weight(nvllm_ctx* ctx, const void* host_w, int dtyp
     if (!ctx || !host_w || !out || N < 1 || K < 1) return fail(ctx, NVLLM_EINVAL, "bad pack_weight arguments");
     if (dtype != NVLLM_DTYPE_F32 && dtype != NVLLM_DTYPE_BF16) return fail(ctx, NVLLM_EINVAL, "dtype %d unsupported", dtype);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const int Np = (N + 15) / 16 * 16, Kp = (K + 31) / 32 * 32;
+    const int Np = (N + 15) / 16 * 16, Kp = (K + 127) / 128 * 128;
     std::vector<uint16_t> tmp((size_t)Np * Kp, 0);
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < K; ++k)
@@ -1105,7 +1218,7 @@ extern "C" int nvllm_op_attention(nvllm_ctx* ctx, const float* q, const float* k
     AttnArgs a;
     a.q = qr; a.kv = kvl; a.block_tables = dbt; a.max_blocks = bps; a.tile_row0 = dt0; a.tile_nrows = dtn; a.tile_slot = dts;
     a.pos = dpos; a.nh_l = nh; a.gqa = gqa; a.out_f32 = out;
-    HIPCHK(ctx, launch_attn_paged(a, nt, qt, s));
+    HIPCHK(ctx, launch_attn_paged(a, nt, qt, rows, 1, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     return NVLLM_OK;
 }
@@ -1144,5 +1257,93 @@ extern "C" int nvllm_op_synth_bf16(nvllm_ctx* ctx, const char* name, uint64_t se
     HIPCHK(ctx, launch_synth_rowmajor_bf16(d, synth_hash_name(name, seed), kind, first, count, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(host_out, d, (size_t)count * 2, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NVLLM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// tuning aid: time one GEMM decomposition on synthetic (random-valued) operands
+// ---------------------------------------------------------------------------------------------------
+extern "C" int nvllm_debug_gemm_bench(nvllm_ctx* ctx, int M, int N, int K, int nt, int nw, int n_split, int iters,
+                                      float* us_per_call) {
+    if (!ctx || !us_per_call || M < 1 || N % 16 || K % 128 || iters < 1) return fail(ctx, NVLLM_EINVAL, "bad gemm_bench arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    GemmPlan p = plan_gemm(M, N, K, 64);
+    if (nt > 0) p.nt = nt;
+    if (nw > 0) p.nw = nw;
+    if (n_split > 0) set_split(p, K / 32, n_split);
+    TmpBufs t;
+    PackedW w; w.N = N; w.K = K;
+    bf16_bits *xh, *xl; float* out;
+    HIPCHK(ctx, t.get(&w.data, (size_t)N * K / 8));
+    HIPCHK(ctx, t.get(&xh, (size_t)M * K)); HIPCHK(ctx, t.get(&xl, (size_t)M * K));
+    HIPCHK(ctx, t.get(&out, (size_t)p.n_split * M * N));
+    HIPCHK(ctx, launch_synth_packed(w, 0, N, 12345, 0, 0, K, s));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(xh, 777, kSynthMatrix, 0, (int64_t)M * K, s));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(xl, 778, kSynthMatrix, 0, (int64_t)M * K, s));
+    for (int i = 0; i < 3; ++i) HIPCHK(ctx, launch_gemm(p, xh, xl, K, w, out, M, s));
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(ctx, launch_gemm(p, xh, xl, K, w, out, M, s));
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *us_per_call = ms * 1e3f / iters;
+    return NVLLM_OK;
+}
+
+// tuning aid: time the decode attention kernel alone on a synthetic cache.  ctx_lens[B] tokens per
+// sequence; part_tokens 0 = no split.  Returns microseconds per launch (attention + combine).
+extern "C" int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int hd, const int32_t* ctx_lens,
+                                      int part_tokens, int iters, float* us_per_call) {
+    if (!ctx || !ctx_lens || !us_per_call || B < 1 || iters < 1 || (hd != 64 && hd != 128) || nh % kv)
+        return fail(ctx, NVLLM_EINVAL, "bad attn_bench arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    TmpBufs t;
+    int max_len = 0, nblk = 0;
+    for (int i = 0; i < B; ++i) max_len = std::max(max_len, (int)ctx_lens[i]);
+    const int bps = (max_len + kBlockTokens - 1) / kBlockTokens;
+    std::vector<int> hbt((size_t)B * bps, 0), hpos(B), hslot(B), ht0(B), htn(B, 1), hts(B);
+    for (int i = 0; i < B; ++i) {
+        for (int j = 0; j < (ctx_lens[i] + kBlockTokens - 1) / kBlockTokens; ++j) hbt[(size_t)i * bps + j] = nblk++;
+        hpos[i] = ctx_lens[i] - 1; hslot[i] = i; ht0[i] = i; hts[i] = i;
+    }
+    KvLayout kvl; kvl.kv_l = kv; kvl.hd = hd;
+    const size_t cache_elems = (size_t)nblk * kv * kBlockTokens * hd;
+    float *q, *po, *pml; bf16_bits *oh, *ol;
+    int *dbt, *dpos, *dslot, *dt0, *dtn, *dts;
+    HIPCHK(ctx, t.get(&kvl.k, cache_elems)); HIPCHK(ctx, t.get(&kvl.v, cache_elems));
+    HIPCHK(ctx, t.get(&q, (size_t)B * nh * hd)); HIPCHK(ctx, t.get(&oh, (size_t)B * nh * hd)); HIPCHK(ctx, t.get(&ol, (size_t)B * nh * hd));
+    HIPCHK(ctx, t.get(&po, (size_t)B * nh * kAttnMaxParts * hd)); HIPCHK(ctx, t.get(&pml, (size_t)B * nh * kAttnMaxParts * 2));
+    HIPCHK(ctx, t.get(&dbt, hbt.size())); HIPCHK(ctx, t.get(&dpos, B)); HIPCHK(ctx, t.get(&dslot, B));
+    HIPCHK(ctx, t.get(&dt0, B)); HIPCHK(ctx, t.get(&dtn, B)); HIPCHK(ctx, t.get(&dts, B));
+    // bf16-valued synthetic bits reinterpreted as f16 are small finite numbers: fine for timing
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(kvl.k, 1, kSynthMatrix, 0, (int64_t)cache_elems, s));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(kvl.v, 2, kSynthMatrix, 0, (int64_t)cache_elems, s));
+    HIPCHK(ctx, launch_synth_rowmajor_f32(q, 3, kSynthMatrix, 0, (int64_t)B * nh * hd, s));
+    HIPCHK(ctx, hipMemcpyAsync(dbt, hbt.data(), hbt.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dpos, hpos.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dslot, hslot.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dt0, ht0.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dtn, htn.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(dts, hts.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    AttnArgs a;
+    a.q = q; a.kv = kvl; a.block_tables = dbt; a.max_blocks = bps; a.tile_row0 = dt0; a.tile_nrows = dtn; a.tile_slot = dts;
+    a.pos = dpos; a.nh_l = nh; a.gqa = nh / kv; a.out_hi = oh; a.out_lo = ol;
+    int parts_max = 1;
+    if (part_tokens > 0) {
+        a.part_tiles = std::max(1, part_tokens / 32); a.max_parts = kAttnMaxParts; a.part_o = po; a.part_ml = pml;
+        parts_max = ((max_len + 31) / 32 + a.part_tiles - 1) / a.part_tiles;
+        if (parts_max > kAttnMaxParts) return fail(ctx, NVLLM_EINVAL, "too many parts");
+    }
+    for (int i = 0; i < 3; ++i) HIPCHK(ctx, launch_attn_paged(a, B, 1, B, parts_max, s));
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(ctx, launch_attn_paged(a, B, 1, B, parts_max, s));
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *us_per_call = ms * 1e3f / iters;
     return NVLLM_OK;
 }

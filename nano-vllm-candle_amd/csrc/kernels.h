@@ -44,9 +44,17 @@ struct GemmPlan {
     int n_split;         // K splits across workgroups (slabs)
     int kt_per_split;
 };
-GemmPlan plan_gemm(int M, int N, int K, int max_split);
+GemmPlan plan_gemm(int M, int N, int K, int max_split);  // K % 128 == 0 required
+void set_split(GemmPlan& p, int KT, int want);
 hipError_t launch_gemm(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
                        float* out, int M, hipStream_t s);
+// same GEMM (n_split must be 1) whose epilogue also emits per-wave partial arg-max (LAST max wins):
+// part_val/part_idx [gemm_argmax_parts(p, N)][M]; `out` may be nullptr (ids only, logits never stored)
+hipError_t launch_gemm_argmax(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
+                              float* out, int M, float* part_val, int* part_idx, hipStream_t s);
+int gemm_argmax_parts(const GemmPlan& p, int N);
+hipError_t launch_argmax_parts(const float* part_val, const int* part_idx, int n_parts, int M, uint32_t* ids,
+                               float* maxval, hipStream_t s);
 
 // ---- (embed +) add + RMSNorm ----------------------------------------------------------------------
 struct NormArgs {
@@ -69,7 +77,7 @@ hipError_t launch_add_rmsnorm(const NormArgs& a, int rows, hipStream_t s);
 
 // ---- q/k norm + RoPE + KV cache write -------------------------------------------------------------
 struct KvLayout {
-    f16_bits* k = nullptr;  // [num_blocks][kv_l][256][hd]  f16 row-major
+    f16_bits* k = nullptr;  // [num_blocks][kv_l][16 tiles][hd/32][64 lanes][8] f16 (QK^T A-fragment packed)
     f16_bits* v = nullptr;  // [num_blocks][kv_l][8 tiles][hd/16][64 lanes][8] f16 (PV A-fragment packed)
     int kv_l = 0, hd = 0;
 };
@@ -107,9 +115,13 @@ struct AttnArgs {
     bf16_bits* out_hi = nullptr;       // [rows][nh_l*hd]
     bf16_bits* out_lo = nullptr;
     float* out_f32 = nullptr;          // optional f32 copy (fine-seam op)
+    // split-KV (decode): each workgroup covers part_tiles 32-token tiles; partials merged by a combine pass
+    int part_tiles = 0, max_parts = 0;
+    float* part_o = nullptr;           // [rows][nh_l][max_parts][hd]
+    float* part_ml = nullptr;          // [rows][nh_l][max_parts][2]
 };
 // qt = q sub-tiles (of 16 MFMA rows) per workgroup: 1 (decode) or 2 (prefill)
-hipError_t launch_attn_paged(const AttnArgs& a, int n_tiles, int qt, hipStream_t s);
+hipError_t launch_attn_paged(const AttnArgs& a, int n_tiles, int qt, int rows, int n_parts_max, hipStream_t s);
 inline int attn_tokens_per_tile(int gqa, int qt) { return (16 / gqa) * qt; }
 
 // ---- SwiGLU -----------------------------------------------------------------------------------------

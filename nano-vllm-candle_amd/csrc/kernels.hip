@@ -158,12 +158,20 @@ hipError_t launch_split_hilo(const float* x, bf16_bits* hi, bf16_bits* lo, int64
 // fragment pair, f32 accumulate: this keeps logits within 1e-3 of the f32 reference.
 // grid = (n-groups, k-splits, m-blocks); k-splits write separate f32 slabs, summed by the consumer.
 // ---------------------------------------------------------------------------------------------------
-template <int MT, int NT, int NW, int KC>
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int MT, int NT, int NW, int KC, bool ARGMAX>
 __global__ void __launch_bounds__(NW * 64)
 gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, int ldx, const uint4* __restrict__ wp,
-            float* __restrict__ out, int M, int N, int KT, int kt_per_split) {
+            float* __restrict__ out, int M, int N, int KT, int kt_per_split, float* __restrict__ part_val,
+            int* __restrict__ part_idx) {
+    // LDS: two buffers of [2 planes][MT][KC][64 lanes] 16-byte slots, filled by LDS-DMA (global_load_lds):
+    // the image is lane-linear per fragment, so every wave-DMA writes one contiguous 1 KiB and every
+    // ds_read_b128 of a fragment is conflict-free.
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    uint4* lds = reinterpret_cast<uint4*>(smem_raw);  // [2 planes][MT][KC][64 lanes]
+    uint4* lds = reinterpret_cast<uint4*>(smem_raw);
+    constexpr int FRAGS = 2 * MT * KC;  // per buffer
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, grp = lane >> 4;
     const int ntiles = N >> 4;
@@ -171,6 +179,7 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
     const int kt_begin = blockIdx.y * kt_per_split;
     const int kt_end = min(KT, kt_begin + kt_per_split);
     const int m0 = blockIdx.z * (MT * 16);
+    const int nchunks = (kt_end - kt_begin + KC - 1) / KC;
 
     f32x4 acc[NT][MT];
 #pragma unroll
@@ -178,67 +187,167 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int kc = kt_begin; kc < kt_end; kc += KC) {
-        const int nk = min(KC, kt_end - kc);
-        // weight fragments of this chunk: global -> VGPR, issued before the LDS staging so they fly meanwhile
-        uint4 wf[NT][KC];
+    // Two named register sets / LDS buffers (static indices only: a runtime-selected set would make
+    // every MFMA depend on the loads still in flight for the other one).
+    uint4 wf0[NT][KC], wf1[NT][KC];
+    // issue the loads of one chunk: weight fragments -> VGPRs, activation fragments -> LDS by DMA.
+    // Rows >= M and k-tiles past the split are clamped to valid addresses: their products are never
+    // stored (rows) or meet zeroed weight fragments (k), so only finiteness matters.
+    auto issue = [&](int c, int buf, uint4 (&w)[NT][KC]) {
+        const int kc = kt_begin + c * KC;
+        // unconditional loads from clamped (always valid) n-tiles: a branch around a load makes hipcc wait
+        // vmcnt(0) after each one (serialised HBM round trips), and so does any immediate use of the data.
+        // The host guarantees every split is a whole number of chunks (K % (32*KC) == 0), so no k masking.
 #pragma unroll
-        for (int a = 0; a < NT; ++a)
+        for (int a = 0; a < NT; ++a) {
+            const int ntc = min(nt0 + a, ntiles - 1);
 #pragma unroll
-            for (int k = 0; k < KC; ++k) {
-                wf[a][k] = make_uint4(0, 0, 0, 0);
-                if (nt0 + a < ntiles && k < nk) wf[a][k] = wp[((size_t)(nt0 + a) * KT + kc + k) * 64 + lane];
-            }
-        __syncthreads();  // previous chunk's LDS reads are done
-        for (int f = wave; f < 2 * MT * KC; f += NW) {
-            const int plane = f / (MT * KC);
-            const int rem = f - plane * (MT * KC);
-            const int mt = rem / KC, k = rem - mt * KC;
-            const int row = m0 + mt * 16 + l15;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < M && k < nk) {
-                const uint16_t* src = (plane ? xl : xh) + (size_t)row * ldx + (size_t)(kc + k) * 32 + grp * 8;
-                v = *reinterpret_cast<const uint4*>(src);
-            }
-            lds[f * 64 + lane] = v;
+            for (int k = 0; k < KC; ++k) w[a][k] = wp[((size_t)ntc * KT + kc + k) * 64 + lane];
         }
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < (FRAGS + NW - 1) / NW; ++i) {
+            const int f = wave + i * NW;
+            if (FRAGS % NW == 0 || f < FRAGS) {
+                const int plane = f / (MT * KC);
+                const int rem = f - plane * (MT * KC);
+                const int mt = rem / KC, k = rem - mt * KC;
+                const int row = min(m0 + mt * 16 + l15, M - 1);
+                const uint16_t* src = (plane ? xl : xh) + (size_t)row * ldx + (size_t)(kc + k) * 32 + grp * 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (size_t)(buf * FRAGS + f) * 64), 16, 0, 0);
+            }
+        }
+    };
+    auto compute = [&](int buf, const uint4 (&w)[NT][KC]) {
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
+            bf16x8 bh[MT], bl[MT];
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {  // all LDS reads of this k-step first, then the MFMAs
+                bh[b] = __builtin_bit_cast(bf16x8, lds[(size_t)(buf * FRAGS + (0 * MT + b) * KC + k) * 64 + lane]);
+                bl[b] = __builtin_bit_cast(bf16x8, lds[(size_t)(buf * FRAGS + (1 * MT + b) * KC + k) * 64 + lane]);
+            }
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                const bf16x8 wv = __builtin_bit_cast(bf16x8, w[a][k]);
+#pragma unroll
+                for (int b = 0; b < MT; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, bl[b], acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // Two chunks are issued up front (both LDS buffers, both register sets): a K-slice of <= 2 chunks --
+    // every decode-shape split -- costs ONE memory round trip instead of two dependent ones.
+    if (nchunks > 0) issue(0, 0, wf0);
+    if (nchunks > 1) issue(1, 1, wf1);
+    for (int c = 0; c < nchunks; c += 2) {
+        __syncthreads();  // vmcnt(0) + barrier: everything issued so far has landed
+        compute(0, wf0);
+        if (c + 2 < nchunks) {
+            __syncthreads();  // WAR: every wave is done reading buffer 0
+            issue(c + 2, 0, wf0);
+        }
+        if (c + 1 >= nchunks) break;
+        compute(1, wf1);  // chunk c+1 landed before the barrier at the top of this iteration
+        if (c + 3 < nchunks) {
+            __syncthreads();
+            issue(c + 3, 1, wf1);
+        }
+    }
+    // D[feature 4*grp+reg][token l15] -> out[token][feature..feature+3]
+    if (out) {
+        float* o = out + (size_t)blockIdx.y * (size_t)M * N;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            if (nt0 + a >= ntiles) continue;
 #pragma unroll
             for (int b = 0; b < MT; ++b) {
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, lds[((0 * MT + b) * KC + k) * 64 + lane]);
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, lds[((1 * MT + b) * KC + k) * 64 + lane]);
-#pragma unroll
-                for (int a = 0; a < NT; ++a) {
-                    const bf16x8 w = __builtin_bit_cast(bf16x8, wf[a][k]);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, bh, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, bl, acc[a][b], 0, 0, 0);
+                const int row = m0 + b * 16 + l15;
+                if (row < M) {
+                    const f32x4 v = acc[a][b];
+                    *reinterpret_cast<float4*>(o + (size_t)row * N + (size_t)(nt0 + a) * 16 + grp * 4) =
+                        make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
     }
-    // D[feature 4*grp+reg][token l15] -> out[token][feature..feature+3]
-    float* o = out + (size_t)blockIdx.y * (size_t)M * N;
-#pragma unroll
-    for (int a = 0; a < NT; ++a) {
-        if (nt0 + a >= ntiles) continue;
+    if constexpr (ARGMAX) {
+        // per-wave partial argmax over its NT*16 features (greedy LM head): LAST max wins
+        // (llm_engine.rs:135-142).  part_*[wave_global][row]; finished by argmax_parts_kernel.
+        const int wg = blockIdx.x * NW + wave;
 #pragma unroll
         for (int b = 0; b < MT; ++b) {
+            float bv = -INFINITY;
+            int bi = -1;
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                if (nt0 + a >= ntiles) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[a][b][r];
+                    const int idx = (nt0 + a) * 16 + grp * 4 + r;
+                    if (bi < 0 || v > bv || (v == bv && idx > bi)) { bv = v; bi = idx; }
+                }
+            }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ov = __shfl_xor(bv, o);
+                const int oi = __shfl_xor(bi, o);
+                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
+            }
             const int row = m0 + b * 16 + l15;
-            if (row < M) {
-                const f32x4 v = acc[a][b];
-                *reinterpret_cast<float4*>(o + (size_t)row * N + (size_t)(nt0 + a) * 16 + grp * 4) =
-                    make_float4(v[0], v[1], v[2], v[3]);
+            if (grp == 0 && row < M) {
+                part_val[(size_t)wg * M + row] = bv;
+                part_idx[(size_t)wg * M + row] = bi;
             }
         }
     }
 }
 
+// finish the fused LM-head argmax: one workgroup per row over n_parts partials
+__global__ void __launch_bounds__(256) argmax_parts_kernel(const float* __restrict__ part_val,
+                                                           const int* __restrict__ part_idx, int n_parts, int M,
+                                                           uint32_t* __restrict__ ids, float* __restrict__ maxval) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int row = blockIdx.x;
+    float bv = -INFINITY;
+    int bi = -1;
+    for (int p = threadIdx.x; p < n_parts; p += blockDim.x) {
+        const float v = part_val[(size_t)p * M + row];
+        const int i = part_idx[(size_t)p * M + row];
+        if (i >= 0 && (bi < 0 || v > bv || (v == bv && i > bi))) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (si[w] >= 0 && (bi < 0 || sv[w] > bv || (sv[w] == bv && si[w] > bi))) { bv = sv[w]; bi = si[w]; }
+        ids[row] = (uint32_t)(bi < 0 ? 0 : bi);
+        if (maxval) maxval[row] = bv;
+    }
+}
+
+// every split covers a whole number of KC-chunks
+void set_split(GemmPlan& p, int KT, int want) {
+    int per = (KT + want - 1) / want;
+    per = (per + p.kc - 1) / p.kc * p.kc;
+    p.kt_per_split = per;
+    p.n_split = (KT + per - 1) / per;
+}
+
 GemmPlan plan_gemm(int M, int N, int K, int max_split) {
     GemmPlan p;
     p.mt = M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 8;
-    p.kc = p.mt == 8 ? 4 : 8;
+    p.kc = p.mt == 8 ? 2 : 4;
     const int rowblocks = (M + 16 * p.mt - 1) / (16 * p.mt);
     const int ntiles = N / 16;
     p.nw = 4;
@@ -247,41 +356,68 @@ GemmPlan plan_gemm(int M, int N, int K, int max_split) {
     const int64_t groups = (int64_t)((ntiles + p.nt * p.nw - 1) / (p.nt * p.nw)) * rowblocks;
     int ns = 1;
     while (groups * ns < 256 && ns * 2 <= max_split && KT / (ns * 2) >= 8) ns *= 2;
-    p.n_split = ns;
-    p.kt_per_split = (KT + ns - 1) / ns;
+    set_split(p, KT, ns);
     return p;
 }
 
-template <int MT, int NT, int NW, int KC>
+template <int MT, int NT, int NW, int KC, bool ARGMAX>
 static hipError_t gemm_launch_t(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
-                                float* out, int M, hipStream_t s) {
+                                float* out, int M, float* part_val, int* part_idx, hipStream_t s) {
     const int ntiles = w.N / 16;
     dim3 grid((ntiles + NT * NW - 1) / (NT * NW), p.n_split, (M + MT * 16 - 1) / (MT * 16));
-    const size_t lds = (size_t)2 * MT * KC * 1024;
+    const size_t lds = (size_t)2 * 2 * MT * KC * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<MT, NT, NW, KC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<MT, NT, NW, KC, ARGMAX>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    gemm_kernel<MT, NT, NW, KC><<<grid, NW * 64, lds, s>>>(xh, xl, ldx, w.data, out, M, w.N, w.K / 32, p.kt_per_split);
+    gemm_kernel<MT, NT, NW, KC, ARGMAX><<<grid, NW * 64, lds, s>>>(xh, xl, ldx, w.data, out, M, w.N, w.K / 32,
+                                                                  p.kt_per_split, part_val, part_idx);
     return hipGetLastError();
+}
+
+template <int NW>
+static hipError_t gemm_dispatch_nw(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
+                                   float* out, int M, float* part_val, int* part_idx, hipStream_t s) {
+#define NVLLM_GEMM_CASE(MT_, NT_, KC_)                                                                              \
+    if (p.mt == MT_ && p.nt == NT_ && p.kc == KC_) {                                                                 \
+        if (part_val) return gemm_launch_t<MT_, NT_, NW, KC_, true>(p, xh, xl, ldx, w, out, M, part_val, part_idx, s); \
+        return gemm_launch_t<MT_, NT_, NW, KC_, false>(p, xh, xl, ldx, w, out, M, nullptr, nullptr, s);               \
+    }
+    NVLLM_GEMM_CASE(1, 1, 4)
+    NVLLM_GEMM_CASE(1, 2, 4)
+    NVLLM_GEMM_CASE(2, 1, 4)
+    NVLLM_GEMM_CASE(2, 2, 4)
+    NVLLM_GEMM_CASE(4, 1, 4)
+    NVLLM_GEMM_CASE(4, 2, 4)
+    NVLLM_GEMM_CASE(8, 1, 2)
+    NVLLM_GEMM_CASE(8, 2, 2)
+#undef NVLLM_GEMM_CASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_gemm(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
                        float* out, int M, hipStream_t s) {
-#define NVLLM_GEMM_CASE(MT_, NT_, KC_) \
-    if (p.mt == MT_ && p.nt == NT_ && p.nw == 4 && p.kc == KC_) return gemm_launch_t<MT_, NT_, 4, KC_>(p, xh, xl, ldx, w, out, M, s);
-    NVLLM_GEMM_CASE(1, 1, 8)
-    NVLLM_GEMM_CASE(1, 2, 8)
-    NVLLM_GEMM_CASE(2, 1, 8)
-    NVLLM_GEMM_CASE(2, 2, 8)
-    NVLLM_GEMM_CASE(4, 1, 8)
-    NVLLM_GEMM_CASE(4, 2, 8)
-    NVLLM_GEMM_CASE(8, 1, 4)
-    NVLLM_GEMM_CASE(8, 2, 4)
-#undef NVLLM_GEMM_CASE
+    return launch_gemm_argmax(p, xh, xl, ldx, w, out, M, nullptr, nullptr, s);
+}
+
+hipError_t launch_gemm_argmax(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
+                              float* out, int M, float* part_val, int* part_idx, hipStream_t s) {
+    if (part_val && p.n_split != 1) return hipErrorInvalidValue;
+    if ((w.K / 32) % p.kc != 0 || p.kt_per_split % p.kc != 0) return hipErrorInvalidValue;
+    if (p.nw == 2) return gemm_dispatch_nw<2>(p, xh, xl, ldx, w, out, M, part_val, part_idx, s);
+    if (p.nw == 4) return gemm_dispatch_nw<4>(p, xh, xl, ldx, w, out, M, part_val, part_idx, s);
+    if (p.nw == 8) return gemm_dispatch_nw<8>(p, xh, xl, ldx, w, out, M, part_val, part_idx, s);
     return hipErrorInvalidValue;
+}
+int gemm_argmax_parts(const GemmPlan& p, int N) { return ((N / 16 + p.nt * p.nw - 1) / (p.nt * p.nw)) * p.nw; }
+
+hipError_t launch_argmax_parts(const float* part_val, const int* part_idx, int n_parts, int M, uint32_t* ids,
+                               float* maxval, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    argmax_parts_kernel<<<M, 256, 0, s>>>(part_val, part_idx, n_parts, M, ids, maxval);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -365,6 +501,13 @@ hipError_t launch_add_rmsnorm(const NormArgs& a, int rows, hipStream_t s) {
 //   token tt (0..31) of a 32-token tile sits in k-slot (g, j): tt<16: g=tt>>2, j=tt&3; else g=(tt-16)>>2, j=4+(tt&3)
 //   element (tt, d) -> (((tile*(hd/16) + d/16)*64 + g*16 + d%16)*8 + j
 // ---------------------------------------------------------------------------------------------------
+// K in QK^T A-fragment order: 16-token tiles, each hd/32 chunks of 1 KiB: lane (g*16 + r) holds token r, dims 32c+8g..+7
+__device__ __forceinline__ size_t k_packed_offset(int t_in_block, int d, int hd) {
+    const int tt = t_in_block >> 4, r = t_in_block & 15;
+    const int c = d >> 5, g = (d & 31) >> 3, j = d & 7;
+    return ((size_t)(tt * (hd >> 5) + c) * 64 + (g << 4) + r) * 8 + j;
+}
+
 __device__ __forceinline__ size_t v_packed_offset(int t_in_block, int d, int hd) {
     const int tile = t_in_block >> 5, tt = t_in_block & 31;
     const int g = (tt & 15) >> 2, j = ((tt >> 4) << 2) | (tt & 3);
@@ -411,9 +554,9 @@ __global__ void __launch_bounds__(256) qk_norm_rope_kvwrite_kernel(QkvArgs a) {
         } else if (act) {
             const int kh = hh - a.nh_l;
             const int blk = a.block_tables[(size_t)a.slot[row] * a.max_blocks + (pos >> 8)];
-            _Float16* k = reinterpret_cast<_Float16*>(a.kv.k) + ((size_t)(blk * kv_l + kh) * kBlockTokens + (pos & 255)) * hd;
-            k[lane] = f16_sat(y1);
-            k[lane + half] = f16_sat(y2);
+            _Float16* k = reinterpret_cast<_Float16*>(a.kv.k) + (size_t)(blk * kv_l + kh) * kBlockTokens * hd;
+            k[k_packed_offset(pos & 255, lane, hd)] = f16_sat(y1);
+            k[k_packed_offset(pos & 255, lane + half, hd)] = f16_sat(y2);
         }
     } else if (act) {  // v head: plain copy into the packed layout
         const int kh = hh - a.nh_l - kv_l;
@@ -443,8 +586,8 @@ __global__ void __launch_bounds__(256) kv_write_plain_kernel(const float* __rest
     const int blk = bt[(size_t)slot[row] * max_blocks + (p >> 8)];
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int kh = i / kv.hd, d = i - kh * kv.hd;
-        _Float16* kd = reinterpret_cast<_Float16*>(kv.k) + ((size_t)(blk * kv.kv_l + kh) * kBlockTokens + (p & 255)) * kv.hd;
-        kd[d] = f16_sat(k[(size_t)row * n + i]);
+        _Float16* kd = reinterpret_cast<_Float16*>(kv.k) + (size_t)(blk * kv.kv_l + kh) * kBlockTokens * kv.hd;
+        kd[k_packed_offset(p & 255, d, kv.hd)] = f16_sat(k[(size_t)row * n + i]);
         _Float16* vd = reinterpret_cast<_Float16*>(kv.v) + (size_t)(blk * kv.kv_l + kh) * kBlockTokens * kv.hd;
         vd[v_packed_offset(p & 255, d, kv.hd)] = f16_sat(v[(size_t)row * n + i]);
     }
@@ -469,12 +612,12 @@ hipError_t launch_kv_write_plain(const float* k, const float* v, int rows, const
 //                                                          from the S accumulators (no lane movement)
 // Both products keep the q row on lane&15, so the online-softmax state (m, l) is per-lane.
 // ---------------------------------------------------------------------------------------------------
-template <int HD, int QT>
-__global__ void __launch_bounds__(256) attn_paged_kernel(AttnArgs a) {
+template <int HD, int QT, int NWV>
+__global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
     constexpr int DC = HD / 32, DT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* ml = reinterpret_cast<float*>(smem_raw);                        // [4][QT][2][16]
-    f32x4* obuf = reinterpret_cast<f32x4*>(smem_raw + 4 * QT * 2 * 16 * 4);  // [3][QT][DT][64]
+    float* ml = reinterpret_cast<float*>(smem_raw);                          // [NWV][QT][2][16]
+    f32x4* obuf = reinterpret_cast<f32x4*>(smem_raw + NWV * QT * 2 * 16 * 4);  // [NWV][QT][DT][64]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, grp = lane >> 4;
@@ -495,6 +638,12 @@ __global__ void __launch_bounds__(256) attn_paged_kernel(AttnArgs a) {
     }
     const int pmax = a.pos[row0 + nrows - 1];
     const int n_kv_tiles = (pmax >> 5) + 1;
+    // split-KV (flash-decoding): workgroup blockIdx.z owns 32-token tiles [t_begin, t_end) and leaves an
+    // un-normalised partial (m, l, O); every workgroup then has the same short dependent-load chain
+    // whatever the context length.  part_tiles == 0: one workgroup does the whole context.
+    const int t_begin = a.part_tiles ? (int)blockIdx.z * a.part_tiles : 0;
+    const int t_end = a.part_tiles ? min(n_kv_tiles, t_begin + a.part_tiles) : n_kv_tiles;
+    if (t_begin >= n_kv_tiles) return;  // uniform for the whole workgroup
 
     f16x8 qh[QT][DC], ql[QT][DC];
 #pragma unroll
@@ -529,22 +678,24 @@ __global__ void __launch_bounds__(256) attn_paged_kernel(AttnArgs a) {
     const int* bt = a.block_tables + (size_t)slot * a.max_blocks;
     const _Float16* kbase = reinterpret_cast<const _Float16*>(a.kv.k);
     const _Float16* vbase = reinterpret_cast<const _Float16*>(a.kv.v);
-    for (int kt = wave; kt < n_kv_tiles; kt += 4) {
+    // one 32-token KV tile: 2*DC K fragments (16 rows x 64 B per wave-load) + DT V fragments (1 KiB each)
+    auto load_tile = [&](int kt, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT]) {  // 16 KiB, all 1 KiB wave-loads
         const int T0 = kt << 5;
         const int blk = bt[T0 >> 8];
         const int tb = T0 & 255;
-        const _Float16* kb = kbase + ((size_t)(blk * kv_l + kh) * kBlockTokens + tb) * HD + grp * 8;
-        uint4 ka[DC], kb2[DC];
+        // packed K: the two 16-token tiles of this 32-token step are 2*DC contiguous 1 KiB fragments
+        const _Float16* kb = kbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 4) * (DC * 512) + lane * 8;
 #pragma unroll
         for (int c = 0; c < DC; ++c) {
-            ka[c] = *reinterpret_cast<const uint4*>(kb + (size_t)l15 * HD + c * 32);
-            kb2[c] = *reinterpret_cast<const uint4*>(kb + (size_t)(16 + l15) * HD + c * 32);
+            ka[c] = *reinterpret_cast<const uint4*>(kb + c * 512);
+            kb2[c] = *reinterpret_cast<const uint4*>(kb + (DC + c) * 512);
         }
         const _Float16* vb = vbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 5) * (DT * 512);
-        uint4 vf[DT];
 #pragma unroll
         for (int d = 0; d < DT; ++d) vf[d] = *reinterpret_cast<const uint4*>(vb + d * 512 + lane * 8);
-
+    };
+    auto compute_tile = [&](int kt, const uint4 (&ka)[DC], const uint4 (&kb2)[DC], const uint4 (&vf)[DT]) {
+        const int T0 = kt << 5;
         const int tokA = T0 + grp * 4, tokB = T0 + 16 + grp * 4;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -587,9 +738,35 @@ __global__ void __launch_bounds__(256) attn_paged_kernel(AttnArgs a) {
                 o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vf[d]), P, acc, 0, 0, 0);
             }
         }
+    };
+    {
+        // Each wave takes every NWV-th 32-token tile.  Decode runs 16 waves per workgroup (one per
+        // 32 tokens up to 512 of context): a sequence's whole K/V is in flight in one HBM round trip.
+        if constexpr (QT == 1) {
+            // decode: two named register sets; the next tile's 16 KiB are in flight while this one is consumed.
+            // Prefetches are unconditional (tile index clamped): no branch around loads.
+            uint4 kaA[DC], kbA[DC], vfA[DT], kaB[DC], kbB[DC], vfB[DT];
+            int kt = t_begin + wave;
+            load_tile(min(kt, t_end - 1), kaA, kbA, vfA);
+            while (kt < t_end) {
+                load_tile(min(kt + NWV, t_end - 1), kaB, kbB, vfB);
+                compute_tile(kt, kaA, kbA, vfA);
+                kt += NWV;
+                if (kt >= t_end) break;
+                load_tile(min(kt + NWV, t_end - 1), kaA, kbA, vfA);
+                compute_tile(kt, kaB, kbB, vfB);
+                kt += NWV;
+            }
+        } else {
+            uint4 ka[DC], kb2[DC], vf[DT];
+            for (int kt = t_begin + wave; kt < t_end; kt += NWV) {
+                load_tile(kt, ka, kb2, vf);
+                compute_tile(kt, ka, kb2, vf);
+            }
+        }
     }
 
-    // combine the 4 waves' partial (m, l, O)
+    // combine the NWV waves' partial (m, l, O)
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         float l = lsum[t];
@@ -607,10 +784,10 @@ __global__ void __launch_bounds__(256) attn_paged_kernel(AttnArgs a) {
     for (int t = 0; t < QT; ++t) {
         float ms = -1e30f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) ms = fmaxf(ms, ml[((w * QT + t) * 2 + 0) * 16 + l15]);
+        for (int w = 0; w < NWV; ++w) ms = fmaxf(ms, ml[((w * QT + t) * 2 + 0) * 16 + l15]);
         float lt = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
+        for (int w = 0; w < NWV; ++w)
             lt += ml[((w * QT + t) * 2 + 1) * 16 + l15] * exp2f(ml[((w * QT + t) * 2 + 0) * 16 + l15] - ms);
         ltot[t] = lt;
         const float f = exp2f(m[t] - ms);
@@ -619,65 +796,126 @@ __global__ void __launch_bounds__(256) attn_paged_kernel(AttnArgs a) {
             o[t][d][0] *= f; o[t][d][1] *= f; o[t][d][2] *= f; o[t][d][3] *= f;
         }
     }
-    if (wave > 0) {
+    // every wave publishes its rescaled O; then wave w sums dim-tiles w, w+NWV, ... over all waves
 #pragma unroll
-        for (int t = 0; t < QT; ++t)
+    for (int t = 0; t < QT; ++t)
 #pragma unroll
-            for (int d = 0; d < DT; ++d) obuf[(((wave - 1) * QT + t) * DT + d) * 64 + lane] = o[t][d];
-    }
+        for (int d = 0; d < DT; ++d) obuf[((wave * QT + t) * DT + d) * 64 + lane] = o[t][d];
     __syncthreads();
-    if (wave == 0) {
+    const int n_parts = a.part_tiles ? (n_kv_tiles + a.part_tiles - 1) / a.part_tiles : 1;
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            if (my_row[t] < 0) continue;
-            const float inv = 1.0f / ltot[t];
-            const size_t base = (size_t)my_row[t] * ldq + (size_t)my_head * HD + grp * 4;
+    for (int t = 0; t < QT; ++t) {
+        if (my_row[t] < 0) continue;
+        const size_t base = (size_t)my_row[t] * ldq + (size_t)my_head * HD + grp * 4;
+        for (int d = wave; d < DT; d += NWV) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int d = 0; d < DT; ++d) {
-                f32x4 acc = o[t][d];
-#pragma unroll
-                for (int w = 0; w < 3; ++w) {
-                    const f32x4 v = obuf[((w * QT + t) * DT + d) * 64 + lane];
-                    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
-                }
-                const float y0 = acc[0] * inv, y1 = acc[1] * inv, y2 = acc[2] * inv, y3 = acc[3] * inv;
-                if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + base + d * 16) = make_float4(y0, y1, y2, y3);
-                if (a.out_hi) {
-                    uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
-                    split_bf16(y0, h0, l0); split_bf16(y1, h1, l1); split_bf16(y2, h2, l2); split_bf16(y3, h3, l3);
-                    *reinterpret_cast<uint2*>(a.out_hi + base + d * 16) =
-                        make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
-                    *reinterpret_cast<uint2*>(a.out_lo + base + d * 16) =
-                        make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
-                }
+            for (int w = 0; w < NWV; ++w) {
+                const f32x4 v = obuf[((w * QT + t) * DT + d) * 64 + lane];
+                acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
             }
+            if (n_parts > 1) {
+                // partial: O (at the workgroup's max) for the combine kernel
+                float* po = a.part_o + (((size_t)my_row[t] * a.nh_l + my_head) * a.max_parts + blockIdx.z) * HD + d * 16 + grp * 4;
+                *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                continue;
+            }
+            const float inv = 1.0f / ltot[t];
+            const float y0 = acc[0] * inv, y1 = acc[1] * inv, y2 = acc[2] * inv, y3 = acc[3] * inv;
+            if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + base + d * 16) = make_float4(y0, y1, y2, y3);
+            if (a.out_hi) {
+                uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
+                split_bf16(y0, h0, l0); split_bf16(y1, h1, l1); split_bf16(y2, h2, l2); split_bf16(y3, h3, l3);
+                *reinterpret_cast<uint2*>(a.out_hi + base + d * 16) =
+                    make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
+                *reinterpret_cast<uint2*>(a.out_lo + base + d * 16) =
+                    make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
+            }
+        }
+        if (n_parts > 1 && wave == 0 && grp == 0) {
+            float ms = -1e30f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) ms = fmaxf(ms, ml[((w * QT + t) * 2 + 0) * 16 + l15]);
+            float* pm = a.part_ml + (((size_t)my_row[t] * a.nh_l + my_head) * a.max_parts + blockIdx.z) * 2;
+            pm[0] = ms;
+            pm[1] = ltot[t];
         }
     }
 }
 
-template <int HD, int QT>
-static hipError_t attn_launch_t(const AttnArgs& a, int n_tiles, hipStream_t s) {
+// merge the split-KV partials of one (row, q head): one wave each, lane = 2 (HD 128) or 1 (HD 64) dims
+template <int HD>
+__global__ void __launch_bounds__(256) attn_combine_kernel(AttnArgs a, int rows) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= rows * a.nh_l) return;
+    const int row = item / a.nh_l, head = item - row * a.nh_l;
+    const int n_parts = (((a.pos[row] >> 5) + 1) + a.part_tiles - 1) / a.part_tiles;
+    if (n_parts <= 1) return;  // the attention kernel wrote the final output itself
+    const float* pm = a.part_ml + ((size_t)row * a.nh_l + head) * a.max_parts * 2;
+    const float* po = a.part_o + ((size_t)row * a.nh_l + head) * a.max_parts * HD;
+    float ms = -1e30f;
+    for (int s = 0; s < n_parts; ++s) ms = fmaxf(ms, pm[2 * s]);
+    float lt = 0.f;
+    constexpr int PER = HD / 64;
+    float acc[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) acc[j] = 0.f;
+    for (int s = 0; s < n_parts; ++s) {
+        const float f = exp2f(pm[2 * s] - ms);
+        lt += pm[2 * s + 1] * f;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) acc[j] += po[(size_t)s * HD + lane * PER + j] * f;
+    }
+    const float inv = 1.0f / lt;
+    const size_t base = (size_t)row * (a.nh_l * HD) + (size_t)head * HD + lane * PER;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const float y = acc[j] * inv;
+        if (a.out_f32) a.out_f32[base + j] = y;
+        if (a.out_hi) {
+            uint16_t h, l;
+            split_bf16(y, h, l);
+            a.out_hi[base + j] = h;
+            a.out_lo[base + j] = l;
+        }
+    }
+}
+
+template <int HD, int QT, int NWV>
+static hipError_t attn_launch_t(const AttnArgs& a, int n_tiles, int grid_z, hipStream_t s) {
     constexpr int DT = HD / 16;
-    const size_t lds = (size_t)4 * QT * 2 * 16 * 4 + (size_t)3 * QT * DT * 64 * 16;
+    const size_t lds = (size_t)NWV * QT * 2 * 16 * 4 + (size_t)NWV * QT * DT * 64 * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_paged_kernel<HD, QT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_paged_kernel<HD, QT, NWV>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid(n_tiles, a.kv.kv_l);
-    attn_paged_kernel<HD, QT><<<grid, 256, lds, s>>>(a);
+    dim3 grid(n_tiles, a.kv.kv_l, grid_z);
+    attn_paged_kernel<HD, QT, NWV><<<grid, NWV * 64, lds, s>>>(a);
     return hipGetLastError();
 }
 
-hipError_t launch_attn_paged(const AttnArgs& a, int n_tiles, int qt, hipStream_t s) {
+// rows: number of q rows (needed by the combine pass); n_parts_max: ceil(max context tiles / part_tiles)
+hipError_t launch_attn_paged(const AttnArgs& a, int n_tiles, int qt, int rows, int n_parts_max, hipStream_t s) {
     if (n_tiles <= 0) return hipSuccess;
     if (a.gqa < 1 || a.gqa > 16) return hipErrorInvalidValue;
-    if (a.kv.hd == 128 && qt == 1) return attn_launch_t<128, 1>(a, n_tiles, s);
-    if (a.kv.hd == 128 && qt == 2) return attn_launch_t<128, 2>(a, n_tiles, s);
-    if (a.kv.hd == 64 && qt == 1) return attn_launch_t<64, 1>(a, n_tiles, s);
-    if (a.kv.hd == 64 && qt == 2) return attn_launch_t<64, 2>(a, n_tiles, s);
-    return hipErrorInvalidValue;
+    const bool split = a.part_tiles > 0 && n_parts_max > 1;
+    if (split && (qt != 1 || !a.part_o || !a.part_ml || n_parts_max > a.max_parts)) return hipErrorInvalidValue;
+    AttnArgs b = a;
+    if (!split) b.part_tiles = 0;
+    const int gz = split ? n_parts_max : 1;
+    hipError_t e = hipErrorInvalidValue;
+    if (a.kv.hd == 128 && qt == 1) e = attn_launch_t<128, 1, 4>(b, n_tiles, gz, s);
+    else if (a.kv.hd == 128 && qt == 2) e = attn_launch_t<128, 2, 4>(b, n_tiles, gz, s);
+    else if (a.kv.hd == 64 && qt == 1) e = attn_launch_t<64, 1, 4>(b, n_tiles, gz, s);
+    else if (a.kv.hd == 64 && qt == 2) e = attn_launch_t<64, 2, 4>(b, n_tiles, gz, s);
+    if (e != hipSuccess || !split) return e;
+    const int items = rows * a.nh_l;
+    if (a.kv.hd == 128) attn_combine_kernel<128><<<(items + 3) / 4, 256, 0, s>>>(b, rows);
+    else attn_combine_kernel<64><<<(items + 3) / 4, 256, 0, s>>>(b, rows);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -239,6 +239,18 @@ class Qwen3ForCausalLM:
                    self.ctx.h)
         return buf
 
+    PROF_KINDS = {"attn": 1, "gemm": 2, "norm": 3, "qk": 4, "silu": 5, "lm_head": 6}
+
+    def profile_kernel(self, kind):
+        """HIP-event bracketing of one kernel class on the library stream (None/0 = off)"""
+        k = self.PROF_KINDS.get(kind, kind) if kind else 0
+        _lib.check(_lib.lib().nvllm_profile_kernel(self.h, int(k)), self.ctx.h)
+
+    def profile_read(self):
+        ms, n = C.c_double(), C.c_int64()
+        _lib.check(_lib.lib().nvllm_profile_read(self.h, C.byref(ms), C.byref(n)), self.ctx.h)
+        return ms.value, n.value
+
     def enable_taps(self, on=True):
         _lib.check(_lib.lib().nvllm_debug_enable_taps(self.h, int(on)), self.ctx.h)
 

@@ -50,3 +50,17 @@ class TPConfig:
 def get_tp():
     """re-reads the environment on every call, like src/tp.rs:68-70"""
     return TPConfig.from_env()
+
+
+def shard_region(cfg, tp_size, tp_rank, hf_name):
+    """(row0, col0, rows, cols) of the full HF tensor owned by this rank -- from the C ABI (host-only call)"""
+    import ctypes as C
+
+    from . import _lib
+
+    out = (C.c_int64 * 4)()
+    cc = cfg.to_c()
+    rc = _lib.lib().nvllm_tp_shard(C.byref(cc), tp_size, tp_rank, hf_name.encode(), out)
+    if rc != 0:
+        raise ValueError(f"no TP shard for {hf_name!r} at tp_size={tp_size}")
+    return tuple(int(v) for v in out)

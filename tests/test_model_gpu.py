@@ -1,0 +1,249 @@
+"""GPU parity tests of the coarse seam (ModelRunner::run contract) through the C ABI: synthetic Qwen3 models on the
+HIP path vs the CPU oracle's dense no-KV-cache forward and vs the committed golden fixture."""
+import numpy as np
+import pytest
+
+from tests.test_golden import load_golden, split_prompts
+from tests.util import LOGITS_TOL, oracle_config, rel_err, row_rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import nano_vllm_candle_amd as p
+
+    return p
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    from nano_vllm_candle_amd import layers
+
+    return layers.default_context()
+
+
+def _tiny_from_golden(pkg, ctx, cfgd, seed):
+    cfg = pkg.Qwen3Config(**{k: cfgd[k] for k in ("vocab_size", "hidden_size", "head_dim", "num_hidden_layers",
+                                                   "num_attention_heads", "num_key_value_heads", "intermediate_size",
+                                                   "max_position_embeddings", "rms_norm_eps", "rope_theta",
+                                                   "bos_token_id", "eos_token_id")})
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=seed, ctx=ctx)
+    m.kv_alloc(num_blocks=16, max_seqs=8, max_batched_tokens=64)
+    return cfg, m
+
+
+@pytest.mark.parametrize("case", ["b1", "b4"])
+def test_golden_prefill_and_32_greedy_steps(pkg, ctx, case):
+    g, cfgd = load_golden()
+    cfg, m = _tiny_from_golden(pkg, ctx, cfgd, int(g["seed"]))
+    seqs = split_prompts(g, case)
+    sids = list(range(100, 100 + len(seqs)))
+    worst = 0.0
+    for step in range(int(g["steps"]) + 1):
+        ids, lg = m.step(sids, seqs, is_prefill=(step == 0), want_logits=True)
+        worst = max(worst, row_rel_err(lg, g[case + "_logits"][step]))
+        assert ids.tolist() == g[case + "_ids"][step].tolist(), f"greedy ids differ at step {step}"
+        for s, t in zip(seqs, ids):
+            s.append(int(t))
+    assert worst < LOGITS_TOL, worst
+
+
+def test_golden_layer_taps(pkg, ctx):
+    g, cfgd = load_golden()
+    cfg, m = _tiny_from_golden(pkg, ctx, cfgd, int(g["seed"]))
+    m.enable_taps(True)
+    seq = split_prompts(g, "b1")
+    m.step([1], seq, is_prefill=True)
+    T = len(seq[0])
+    for l in range(cfg.num_hidden_layers):
+        assert rel_err(m.layer_tap(l, 0, T), g["b1_layer_h"][l]) < LOGITS_TOL
+        assert rel_err(m.layer_tap(l, 1, T), g["b1_layer_res"][l]) < LOGITS_TOL
+
+
+def test_decode_next_device_feedback_equals_step(pkg, ctx):
+    g, cfgd = load_golden()
+    cfg, m = _tiny_from_golden(pkg, ctx, cfgd, int(g["seed"]))
+    seqs = split_prompts(g, "b4")
+    ids, _ = m.step([0, 1, 2, 3], seqs, is_prefill=True)
+    assert ids.tolist() == g["b4_ids"][0].tolist()
+    for step in range(1, 12):
+        nxt = m.decode_next()[:4]
+        assert nxt.tolist() == g["b4_ids"][step].tolist()
+
+
+def test_seq_free_returns_blocks_and_ids_can_restart(pkg, ctx):
+    cfg = pkg.Qwen3Config.tiny()
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=3, ctx=ctx)
+    m.kv_alloc(num_blocks=4, max_seqs=2, max_batched_tokens=512)
+    assert m.free_blocks() == 4
+    a, la = m.step([7], [list(range(1, 301))], is_prefill=True, want_logits=True)  # 300 tokens -> 2 blocks
+    assert m.free_blocks() == 2
+    with pytest.raises(pkg._lib.NvllmError) as e:  # 2 more sequences of 300 do not fit
+        m.step([8, 9], [list(range(1, 301))] * 2, is_prefill=True)
+    assert e.value.code == pkg._lib.ENOMEM
+    m.seq_free(7)
+    m.seq_free(8)
+    m.seq_free(9)
+    assert m.free_blocks() == 4
+    b, lb = m.step([7], [list(range(1, 301))], is_prefill=True, want_logits=True)
+    assert a.tolist() == b.tolist() and np.array_equal(la, lb)  # deterministic, stale cache content is harmless
+
+
+def test_errors_are_codes_not_crashes(pkg, ctx):
+    cfg = pkg.Qwen3Config.tiny()
+    m = pkg.Qwen3ForCausalLM(cfg, ctx)
+    with pytest.raises(pkg._lib.NvllmError) as e:
+        m.finalize()  # tensors missing
+    assert e.value.code == pkg._lib.ESTATE
+    with pytest.raises(pkg._lib.NvllmError):
+        m.load_tensor("model.layers.0.bogus.weight", np.zeros((2, 2), np.float32))
+    with pytest.raises(pkg._lib.NvllmError):
+        m.load_tensor("model.norm.weight", np.zeros((7,), np.float32))  # wrong shape
+    m2 = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
+    with pytest.raises(pkg._lib.NvllmError) as e:
+        m2.step([0], [[1, 2]], True)  # kv_alloc not called
+    assert e.value.code == pkg._lib.ESTATE
+    m2.kv_alloc(4, 2, 64)
+    with pytest.raises(pkg._lib.NvllmError) as e:
+        m2.step([0], [[1, 99999]], True)  # token out of range
+    assert e.value.code == pkg._lib.EINVAL
+    ids, _ = m2.step([], [], True)  # empty batch -> empty result (llm_engine.rs:147-149)
+    assert ids.size == 0
+
+
+def test_runner_maps_errors_to_eos_like_the_reference(pkg, ctx):
+    from nano_vllm_candle_amd.engine import Qwen3ModelRunner, SamplingParams, Sequence
+
+    cfg = pkg.Qwen3Config.tiny()
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
+    m.kv_alloc(1, 1, 64)
+    r = Qwen3ModelRunner(m)
+    seqs = [Sequence([1, 2, 3], SamplingParams()), Sequence([4, 5], SamplingParams())]  # 2 seqs > max_seqs 1
+    assert r.run(seqs, True) == [cfg.eos_token_id] * 2 and r.last_error is not None  # llm_engine.rs:153-175
+
+
+def test_loaded_state_dict_equals_synthetic_and_tied_lm_head(pkg, ctx, oracle):
+    cfg = pkg.Qwen3Config.tiny()
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(11)
+    tensors = {n: om.get_tensor(n, s) for n, s in cfg.hf_tensor_shapes().items()}
+    a = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 11, ctx)
+    b = pkg.Qwen3ForCausalLM.from_state_dict(cfg, tensors, ctx)  # f32 host tensors through load_tensor
+    for m in (a, b):
+        m.kv_alloc(4, 2, 64)
+    seq = [[3, 1, 4, 1, 5, 9, 2, 6]]
+    ia, la = a.step([0], seq, True, want_logits=True)
+    ib, lb = b.step([0], seq, True, want_logits=True)
+    assert ia.tolist() == ib.tolist() and np.array_equal(la, lb)
+    # tied embeddings: no lm_head.weight in the checkpoint -> LM head = embedding table
+    tied = dict(tensors)
+    del tied["lm_head.weight"]
+    c = pkg.Qwen3ForCausalLM.from_state_dict(cfg, tied, ctx)
+    c.kv_alloc(4, 2, 64)
+    om.set_tensor("lm_head.weight", tensors["model.embed_tokens.weight"])
+    ic, lc = c.step([0], seq, True, want_logits=True)
+    rid, rl = om.run_greedy(seq)
+    assert ic.tolist() == rid.tolist() and row_rel_err(lc, rl) < LOGITS_TOL
+
+
+@pytest.mark.parametrize("kw", [dict(num_attention_heads=8, num_key_value_heads=2, head_dim=64, hidden_size=256),   # GQA 4
+                                dict(num_attention_heads=2, num_key_value_heads=2, head_dim=128, hidden_size=128),  # MHA
+                                dict(num_attention_heads=8, num_key_value_heads=1, head_dim=128, hidden_size=256,
+                                     intermediate_size=384, num_hidden_layers=3)])                                  # GQA 8
+def test_other_head_layouts_vs_oracle(pkg, ctx, oracle, kw):
+    cfg = pkg.Qwen3Config.tiny(**kw)
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 5, ctx)
+    m.kv_alloc(8, 4, 48)
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(5)
+    rng = np.random.default_rng(2)
+    seqs = [rng.integers(0, cfg.vocab_size, n).tolist() for n in (9, 70, 2)]  # 70 > 48: chunked prefill
+    for step in range(5):
+        ids, lg = m.step([0, 1, 2], seqs, step == 0, want_logits=True)
+        rid, rlg = om.run_greedy(seqs)
+        assert row_rel_err(lg, rlg) < LOGITS_TOL
+        assert ids.tolist() == rid.tolist()
+        for s, t in zip(seqs, rid):
+            s.append(int(t))
+
+
+def test_context_crossing_a_block_boundary(pkg, ctx, oracle):
+    # prompt 250, 12 decode steps: the sequence grows past one 256-token KV block
+    cfg = pkg.Qwen3Config.tiny()
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 1, ctx)
+    m.kv_alloc(4, 2, 512)
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(1)
+    seq = [np.random.default_rng(9).integers(0, cfg.vocab_size, 250).tolist()]
+    for step in range(12):
+        ids, lg = m.step([0], seq, step == 0, want_logits=True)
+        rid, rlg = om.run_greedy(seq)
+        assert row_rel_err(lg, rlg) < LOGITS_TOL and ids.tolist() == rid.tolist()
+        seq[0].append(int(rid[0]))
+
+
+def test_engine_continuous_batching_matches_single_sequence_runs(pkg, ctx):
+    # configs[2] in miniature: prefill-first scheduling with max_num_seqs 3; every request's tokens must equal
+    # the tokens it gets when it runs alone (sequences are independent; batching must not leak state)
+    from nano_vllm_candle_amd.engine import LLMEngine, Qwen3ModelRunner, SamplingParams, Scheduler, SchedulerConfig
+
+    cfg = pkg.Qwen3Config.tiny()
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 2, ctx)
+    # the reference's prefill-first scheduler admits waiting sequences regardless of how many are running
+    # (scheduler.rs:113-157 counts only the prefill batch), so the native pool needs a slot per admitted request
+    m.kv_alloc(16, 8, 64)
+    rng = np.random.default_rng(3)
+    prompts = [rng.integers(3, cfg.vocab_size, n).tolist() for n in (4, 30, 11, 2, 17)]
+    sp = SamplingParams(max_tokens=6, ignore_eos=True)
+
+    def run(ps, max_num_seqs):
+        eng = LLMEngine(Scheduler(SchedulerConfig(max_num_seqs=max_num_seqs, eos=cfg.eos_token_id)),
+                        Qwen3ModelRunner(m, raise_errors=True))
+        return [toks for _, toks in eng.generate(ps, sp)]
+
+    batched = run(prompts, 3)
+    alone = [run([p], 1)[0] for p in prompts]
+    assert batched == alone
+    assert m.free_blocks() == 16  # every finished sequence released its blocks
+
+
+def test_qwen3_0_6b_shapes_vs_oracle(pkg, ctx, oracle):
+    # configs[0]/[1] at the real shapes: 1 sequence, prompt 16, greedy steps (CPU oracle: full recompute each step)
+    cfg = pkg.Qwen3Config.qwen3_0_6b()
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
+    m.kv_alloc(4, 2, 256)
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(0)
+    seq = [np.random.default_rng(0).integers(0, cfg.vocab_size, 16).tolist()]
+    worst = 0.0
+    for step in range(6):
+        ids, lg = m.step([0], seq, step == 0, want_logits=True)
+        rid, rlg = om.run_greedy(seq)
+        worst = max(worst, row_rel_err(lg, rlg))
+        srt = np.sort(rlg[0])
+        margin = (srt[-1] - srt[-2]) / np.abs(rlg[0]).max()
+        if margin > 2 * LOGITS_TOL:  # a near-tie inside the tolerance may legitimately flip
+            assert ids.tolist() == rid.tolist(), f"step {step}"
+        seq[0].append(int(rid[0]))
+    assert worst < LOGITS_TOL, worst
+
+
+def test_full_size_batch64_properties(pkg, ctx):
+    # BASELINE configs[2] size (0.6B, 64 live sequences): size-independent properties
+    cfg = pkg.Qwen3Config.qwen3_0_6b()
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
+    m.kv_alloc(64 * 3, 64, 4096)
+    rng = np.random.default_rng(0)
+    prompts = [rng.integers(0, cfg.vocab_size, int(n)).tolist() for n in rng.integers(64, 513, 64)]
+    ids, lg = m.step(list(range(64)), prompts, True, want_logits=True)
+    # tests/layer_test.rs:70,354-357 (no NaN/Inf, non-degenerate); synthetic weights give logit sigma ~0.58
+    assert np.isfinite(lg).all() and lg.var() > 0.1
+    assert ids.tolist() == [int(np.flatnonzero(r == r.max())[-1]) for r in lg]  # device argmax == last max of its logits
+    # a sequence computed alone gives the same last-row logits as inside the batch (no cross-sequence leakage)
+    m2 = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
+    m2.kv_alloc(4, 1, 4096)
+    for i in (0, 37):
+        _, l1 = m2.step([0], [prompts[i]], True, want_logits=True)
+        assert rel_err(l1[0], lg[i]) < 1e-5
+    # decode continues deterministically: two identical runs agree bit for bit
+    a = [m.decode_next()[:64].copy() for _ in range(3)]
+    m.step(list(range(64)), prompts, True)
+    b = [m.decode_next()[:64].copy() for _ in range(3)]
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
