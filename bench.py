@@ -195,7 +195,7 @@ def main():
                           "event_ms_per_step": ev_ms / a.steps},
         "kernel_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
     }
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:  # reported at N=1 only (driver contract)
         out["cpu_baseline"] = cpu_baseline(cfg, prompts, a.cpu_seqs, a.seed)
     if rank == 0:
         print(json.dumps(out), flush=True)

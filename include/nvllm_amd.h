@@ -68,6 +68,9 @@ const char* nvllm_last_error(const nvllm_ctx* ctx);
 int nvllm_rccl_unique_id(void* out_id /* NVLLM_RCCL_ID_BYTES */);
 /* tp_size==1: rccl_id may be NULL.  tp_rank >= tp_size is folded to 0 like src/tp.rs:24-29. */
 int nvllm_ctx_create(int device_ordinal, int tp_rank, int tp_size, const void* rccl_id, nvllm_ctx** out);
+/* TEST-ONLY communicator: the tp_size contexts created with the same `group` name by different host threads of
+ * one process exchange through host memory instead of RCCL (exercises every TP code path on a single GPU). */
+int nvllm_ctx_create_loopback(int device_ordinal, int tp_rank, int tp_size, const char* group, nvllm_ctx** out);
 int nvllm_ctx_destroy(nvllm_ctx* ctx);
 int nvllm_ctx_synchronize(nvllm_ctx* ctx);
 /* hipStream_t every library launch goes to (time it with HIP events recorded on THIS stream) */

@@ -41,6 +41,7 @@ _SIGS = {
     "nvllm_last_error": (C.c_char_p, [_vp]),
     "nvllm_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "nvllm_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(_vp)]),
+    "nvllm_ctx_create_loopback": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_vp)]),
     "nvllm_ctx_destroy": (C.c_int, [_vp]),
     "nvllm_ctx_synchronize": (C.c_int, [_vp]),
     "nvllm_ctx_stream": (C.c_void_p, [_vp]),

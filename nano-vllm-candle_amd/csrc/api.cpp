@@ -7,8 +7,13 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -23,7 +28,23 @@ using namespace nvllm;
 // ---------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------
+// In-process loopback communicator (tests only): contexts created with the same group name by different
+// host threads of ONE process exchange through host memory.  It exercises every tensor-parallel code path
+// (sharded load, per-rank kernels, all-reduce placement, vocab-parallel arg-max) on a single GPU; production
+// uses RCCL.
+struct LoopGroup {
+    std::mutex mu;
+    std::condition_variable cv;
+    int size = 0, arrived = 0;
+    uint64_t generation = 0;
+    std::vector<float> acc;
+    std::vector<unsigned char> gather;
+};
+static std::mutex g_groups_mu;
+static std::map<std::string, std::shared_ptr<LoopGroup>> g_groups;
+
 struct nvllm_ctx {
+    std::shared_ptr<LoopGroup> loop;
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -54,6 +75,70 @@ static int fail(nvllm_ctx* ctx, int code, const char* fmt, ...) {
         ncclResult_t r_ = (expr);                                                                        \
         if (r_ != ncclSuccess) return fail(ctx, NVLLM_ERCCL, "%s -> %s", #expr, ncclGetErrorString(r_)); \
     } while (0)
+
+// ---- collectives: RCCL on the library stream, or the in-process loopback group ----------------------
+static int comm_allreduce_sum(nvllm_ctx* ctx, float* buf, size_t n) {
+    if (ctx->tp_size == 1) return NVLLM_OK;
+    if (!ctx->loop) {
+        NCCLCHK(ctx, ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, ctx->comm, ctx->stream));
+        return NVLLM_OK;
+    }
+    std::vector<float> host(n);
+    HIPCHK(ctx, hipMemcpyAsync(host.data(), buf, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    LoopGroup& g = *ctx->loop;
+    {
+        std::unique_lock<std::mutex> lk(g.mu);
+        const uint64_t gen = g.generation;
+        if (g.arrived == 0) g.acc.assign(n, 0.f);
+        // ranks add in arrival order: like RCCL, the order of the sum is not the TP=1 order
+        for (size_t i = 0; i < n; ++i) g.acc[i] += host[i];
+        if (++g.arrived == g.size) { g.arrived = 0; ++g.generation; g.cv.notify_all(); }
+        else g.cv.wait(lk, [&] { return g.generation != gen; });
+        host = g.acc;  // every rank reads the same bytes
+    }
+    // second phase so nobody re-initialises acc while a slow rank still copies it
+    {
+        std::unique_lock<std::mutex> lk(g.mu);
+        const uint64_t gen = g.generation;
+        if (++g.arrived == g.size) { g.arrived = 0; ++g.generation; g.cv.notify_all(); }
+        else g.cv.wait(lk, [&] { return g.generation != gen; });
+    }
+    HIPCHK(ctx, hipMemcpyAsync(buf, host.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NVLLM_OK;
+}
+
+// recv[r*bytes .. ) = rank r's send (send may alias recv + rank*bytes)
+static int comm_allgather(nvllm_ctx* ctx, const void* send, void* recv, size_t bytes) {
+    if (!ctx->loop) {
+        NCCLCHK(ctx, ncclAllGather(send, recv, bytes, ncclUint8, ctx->comm, ctx->stream));
+        return NVLLM_OK;
+    }
+    std::vector<unsigned char> host(bytes);
+    HIPCHK(ctx, hipMemcpyAsync(host.data(), send, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    LoopGroup& g = *ctx->loop;
+    std::vector<unsigned char> all;
+    {
+        std::unique_lock<std::mutex> lk(g.mu);
+        const uint64_t gen = g.generation;
+        if (g.arrived == 0) g.gather.assign(bytes * g.size, 0);
+        memcpy(g.gather.data() + (size_t)ctx->tp_rank * bytes, host.data(), bytes);
+        if (++g.arrived == g.size) { g.arrived = 0; ++g.generation; g.cv.notify_all(); }
+        else g.cv.wait(lk, [&] { return g.generation != gen; });
+        all = g.gather;
+    }
+    {
+        std::unique_lock<std::mutex> lk(g.mu);
+        const uint64_t gen = g.generation;
+        if (++g.arrived == g.size) { g.arrived = 0; ++g.generation; g.cv.notify_all(); }
+        else g.cv.wait(lk, [&] { return g.generation != gen; });
+    }
+    HIPCHK(ctx, hipMemcpyAsync(recv, all.data(), all.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NVLLM_OK;
+}
 
 extern "C" const char* nvllm_last_error(const nvllm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -98,6 +183,20 @@ extern "C" int nvllm_ctx_create(int device_ordinal, int tp_rank, int tp_size, co
         }
     }
     *out = c;
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_ctx_create_loopback(int device_ordinal, int tp_rank, int tp_size, const char* group, nvllm_ctx** out) {
+    if (!out || !group || tp_size < 1 || tp_rank < 0 || tp_rank >= tp_size) return fail(nullptr, NVLLM_EINVAL, "bad loopback arguments");
+    int rc = nvllm_ctx_create(device_ordinal, 0, 1, nullptr, out);
+    if (rc) return rc;
+    (*out)->tp_rank = tp_rank;
+    (*out)->tp_size = tp_size;
+    std::lock_guard<std::mutex> lk(g_groups_mu);
+    auto& g = g_groups[group];
+    if (!g) { g = std::make_shared<LoopGroup>(); g->size = tp_size; }
+    if (g->size != tp_size) { nvllm_ctx_destroy(*out); *out = nullptr; return fail(nullptr, NVLLM_EINVAL, "loopback group size mismatch"); }
+    (*out)->loop = g;
     return NVLLM_OK;
 }
 
@@ -206,12 +305,13 @@ struct nvllm_model {
     int *d_pos = nullptr, *d_slot = nullptr, *d_tile_row0 = nullptr, *d_tile_nrows = nullptr, *d_tile_slot = nullptr,
         *d_last_rows = nullptr;
     float *resid = nullptr, *slabs = nullptr, *qbuf = nullptr, *logits = nullptr, *d_maxval = nullptr, *red = nullptr;
-    bf16_bits *xh = nullptr, *xl = nullptr;
+    bf16_bits *xh = nullptr, *xl = nullptr, *xh2 = nullptr, *xl2 = nullptr;
     uint32_t* d_next = nullptr;
     float *attn_po = nullptr, *attn_pml = nullptr;  // split-KV partials [max_seqs][nh_l][kAttnMaxParts][hd] / [..][2]
     int attn_part_tiles = 4, attn_parts_max = 1;   // this step's split geometry (decode only)
     float* part_val = nullptr;  // fused LM-head arg-max partials [V_l/16][max_seqs]
     int* part_idx = nullptr;
+    unsigned long long* argmax_scratch = nullptr;  // ticket + per-row keys of argmax_parts_kernel
     bool want_logits = false;   // this step stores the last-row logits
     int cur_n = 0;              // sequences of the step in flight
     size_t slab_floats = 0;
@@ -325,11 +425,11 @@ static void free_kv(nvllm_model* m) {
     for (auto p : m->vcache) (void)hipFree(p);
     m->kcache.clear(); m->vcache.clear();
     void* ptrs[] = {m->d_block_tables, m->d_ids, m->d_pos, m->d_slot, m->d_tile_row0, m->d_tile_nrows, m->d_tile_slot,
-                    m->d_last_rows, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->d_next,
-                    m->part_val, m->part_idx, m->attn_po, m->attn_pml, m->tap_h, m->tap_res, m->cosv, m->sinv};
+                    m->d_last_rows, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->xh2, m->xl2, m->d_next,
+                    m->part_val, m->part_idx, m->argmax_scratch, m->attn_po, m->attn_pml, m->tap_h, m->tap_res, m->cosv, m->sinv};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     m->d_block_tables = nullptr; m->d_ids = nullptr; m->d_pos = m->d_slot = m->d_tile_row0 = m->d_tile_nrows = m->d_tile_slot = m->d_last_rows = nullptr;
-    m->resid = m->slabs = m->qbuf = m->logits = m->d_maxval = m->red = nullptr; m->xh = m->xl = nullptr; m->d_next = nullptr; m->part_val = nullptr; m->part_idx = nullptr; m->attn_po = m->attn_pml = nullptr;
+    m->resid = m->slabs = m->qbuf = m->logits = m->d_maxval = m->red = nullptr; m->xh = m->xl = m->xh2 = m->xl2 = nullptr; m->d_next = nullptr; m->part_val = nullptr; m->part_idx = nullptr; m->argmax_scratch = nullptr; m->attn_po = m->attn_pml = nullptr;
     m->tap_h = m->tap_res = nullptr; m->cosv = m->sinv = nullptr;
     if (m->h_stage) (void)hipHostFree(m->h_stage);
     m->h_stage = nullptr;
@@ -361,6 +461,7 @@ struct Target {
     int64_t full_rows = 0, full_cols = 0;  // HF shape
     int64_t r0 = 0, c0 = 0, rows = 0, cols = 0;  // shard region
     int dst_row0 = 0;
+    int ileave = -1;  // gate (0) / up (1): interleaved 16-row tiles
     int synth_kind = kSynthMatrix;
 };
 
@@ -386,8 +487,8 @@ static bool resolve(nvllm_model* m, const char* name, Target& t) {
     if (!strcmp(s, "self_attn.k_proj.weight")) { t.w = &w.qkv; t.full_rows = kv * hd; t.full_cols = H; t.r0 = rank * kr; t.rows = kr; t.cols = H; t.dst_row0 = (int)qr; return true; }
     if (!strcmp(s, "self_attn.v_proj.weight")) { t.w = &w.qkv; t.full_rows = kv * hd; t.full_cols = H; t.r0 = rank * kr; t.rows = kr; t.cols = H; t.dst_row0 = (int)(qr + kr); return true; }
     if (!strcmp(s, "self_attn.o_proj.weight")) { t.w = &w.o; t.full_rows = H; t.full_cols = nh * hd; t.c0 = rank * qr; t.rows = H; t.cols = qr; return true; }
-    if (!strcmp(s, "mlp.gate_proj.weight")) { t.w = &w.gu; t.full_rows = I; t.full_cols = H; t.r0 = (int64_t)rank * m->I_l; t.rows = m->I_l; t.cols = H; t.dst_row0 = 0; return true; }
-    if (!strcmp(s, "mlp.up_proj.weight")) { t.w = &w.gu; t.full_rows = I; t.full_cols = H; t.r0 = (int64_t)rank * m->I_l; t.rows = m->I_l; t.cols = H; t.dst_row0 = m->I_l; return true; }
+    if (!strcmp(s, "mlp.gate_proj.weight")) { t.w = &w.gu; t.full_rows = I; t.full_cols = H; t.r0 = (int64_t)rank * m->I_l; t.rows = m->I_l; t.cols = H; t.dst_row0 = 0; t.ileave = 0; return true; }
+    if (!strcmp(s, "mlp.up_proj.weight")) { t.w = &w.gu; t.full_rows = I; t.full_cols = H; t.r0 = (int64_t)rank * m->I_l; t.rows = m->I_l; t.cols = H; t.dst_row0 = 0; t.ileave = 1; return true; }
     if (!strcmp(s, "mlp.down_proj.weight")) { t.w = &w.down; t.full_rows = H; t.full_cols = I; t.c0 = (int64_t)rank * m->I_l; t.rows = H; t.cols = m->I_l; return true; }
     t.kind = Target::F32VEC; t.synth_kind = kSynthNorm; t.full_rows = 1; t.rows = 1;
     if (!strcmp(s, "input_layernorm.weight")) { t.f = w.ln1; t.full_cols = t.cols = H; return true; }
@@ -440,7 +541,7 @@ extern "C" int nvllm_model_load_tensor(nvllm_model* m, const char* hf_name, cons
             bf16_bits* dtmp = nullptr;
             HIPCHK(ctx, hipMalloc((void**)&dtmp, n * 2));
             hipError_t e = hipMemcpy(dtmp, tmp.data(), n * 2, hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = launch_pack_rows(*t.w, t.dst_row0, (int)t.rows, dtmp, t.cols, ctx->stream);
+            if (e == hipSuccess) e = launch_pack_rows(*t.w, t.dst_row0, (int)t.rows, dtmp, t.cols, t.ileave, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             (void)hipFree(dtmp);
             HIPCHK(ctx, e);
@@ -460,7 +561,7 @@ static int synth_one(nvllm_model* m, const char* name, uint64_t seed) {
     } else if (t.kind == Target::BF16ROWS) {
         HIPCHK(ctx, launch_synth_rowmajor_bf16(t.b, nh, kSynthMatrix, 0, t.rows * t.cols, ctx->stream));
     } else {
-        HIPCHK(ctx, launch_synth_packed(*t.w, t.dst_row0, (int)t.rows, nh, t.r0, t.c0, t.full_cols, ctx->stream));
+        HIPCHK(ctx, launch_synth_packed(*t.w, t.dst_row0, (int)t.rows, nh, t.r0, t.c0, t.full_cols, t.ileave, ctx->stream));
     }
     m->loaded[name] = true;
     return NVLLM_OK;
@@ -522,7 +623,7 @@ extern "C" int nvllm_model_finalize(nvllm_model* m) {
         }
     if (!m->loaded.count("lm_head.weight")) {
         // tied embeddings: LM head = this rank's vocab rows of the embedding table
-        HIPCHK(ctx, launch_pack_rows(m->lm_head, 0, m->V_l, m->embed + (size_t)ctx->tp_rank * m->V_l * m->H, m->H, ctx->stream));
+        HIPCHK(ctx, launch_pack_rows(m->lm_head, 0, m->V_l, m->embed + (size_t)ctx->tp_rank * m->V_l * m->H, m->H, -1, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     m->finalized = true;
@@ -590,11 +691,16 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->d_maxval, (size_t)max_seqs * std::max(1, ctx->tp_size) * 2);
     if (!rc) rc = dmalloc(ctx, &m->xh, R * wide);
     if (!rc) rc = dmalloc(ctx, &m->xl, R * wide);
+    if (!rc) rc = dmalloc(ctx, &m->xh2, R * (size_t)m->I_l);
+    if (!rc) rc = dmalloc(ctx, &m->xl2, R * (size_t)m->I_l);
     if (!rc) rc = dmalloc(ctx, &m->d_next, (size_t)max_seqs * (ctx->tp_size + 1));
     if (!rc) rc = dmalloc(ctx, &m->attn_po, (size_t)max_seqs * m->nh_l * kAttnMaxParts * m->hd);
     if (!rc) rc = dmalloc(ctx, &m->attn_pml, (size_t)max_seqs * m->nh_l * kAttnMaxParts * 2);
-    if (!rc) rc = dmalloc(ctx, &m->part_val, (size_t)(m->V_l / 16) * max_seqs);
-    if (!rc) rc = dmalloc(ctx, &m->part_idx, (size_t)(m->V_l / 16) * max_seqs);
+    // one partial per LM-head wave: at most V_l/16 n-tiles rounded up to whole workgroups (<= 8 waves each)
+    if (!rc) rc = dmalloc(ctx, &m->part_val, (size_t)(m->V_l / 16 + 16) * max_seqs);
+    if (!rc) rc = dmalloc(ctx, &m->part_idx, (size_t)(m->V_l / 16 + 16) * max_seqs);
+    if (!rc) rc = dmalloc(ctx, &m->argmax_scratch, (size_t)max_seqs + 1);
+    if (!rc) HIPCHK(ctx, hipMemsetAsync(m->argmax_scratch, 0, ((size_t)max_seqs + 1) * 8, ctx->stream));
     if (rc) return rc;
     m->h_stage_bytes = (R * 6 + (size_t)max_seqs * 4) * sizeof(int) + 256;
     HIPCHK(ctx, hipHostMalloc(&m->h_stage, m->h_stage_bytes, hipHostMallocDefault));
@@ -675,7 +781,8 @@ static int tp_reduce(nvllm_model* m, int rows, int ns, const float** in, int* n_
     nvllm_ctx* ctx = m->ctx;
     if (ctx->tp_size == 1) { *in = m->slabs; *n_slabs = ns; return NVLLM_OK; }
     HIPCHK(ctx, launch_slab_sum(m->slabs, ns, (int64_t)rows * m->H, nullptr, rows, m->H, m->red, ctx->stream));
-    NCCLCHK(ctx, ncclAllReduce(m->red, m->red, (size_t)rows * m->H, ncclFloat, ncclSum, ctx->comm, ctx->stream));
+    int rc_ = comm_allreduce_sum(ctx, m->red, (size_t)rows * m->H);
+    if (rc_) return rc_;
     *in = m->red;
     *n_slabs = 1;
     return NVLLM_OK;
@@ -711,11 +818,16 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         qa.q_scale = powf((float)hd, -0.5f) * 1.4426950408889634f;  // head_dim^-0.5 (qwen3.rs:134) * log2(e)
         qa.q_out = m->qbuf;
         qa.kv.k = m->kcache[l]; qa.kv.v = m->vcache[l]; qa.kv.kv_l = m->kv_l; qa.kv.hd = hd;
-        PROF(m, PROF_QK, launch_qk_norm_rope_kvwrite(qa, R, s));
+        const bool fuse_qk = qt == 1 && n_tiles == R;  // decode: every q-tile is one row
+        if (!fuse_qk) PROF(m, PROF_QK, launch_qk_norm_rope_kvwrite(qa, R, s));
         AttnArgs aa;
         aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
         aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
         aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->xh; aa.out_lo = m->xl;
+        if (fuse_qk) {
+            aa.qkv = qa.qkv; aa.n_slabs = qa.n_slabs; aa.slab_stride = qa.slab_stride; aa.ldqkv = NQ; aa.qn = w.qn; aa.kn = w.kn;
+            aa.cos = m->cosv; aa.sin = m->sinv; aa.eps = eps; aa.q_scale = qa.q_scale;
+        }
         int parts_max = 1;
         if (qt == 1 && R <= m->max_seqs) {  // decode rows: split the context over workgroups
             aa.part_tiles = m->attn_part_tiles; aa.max_parts = kAttnMaxParts; aa.part_o = m->attn_po; aa.part_ml = m->attn_pml;
@@ -734,11 +846,11 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         nb.weight = w.ln2; nb.eps = eps; nb.H = H; nb.xh = m->xh; nb.xl = m->xl;
         PROF(m, PROF_NORM, launch_add_rmsnorm(nb, R, s));
         // MLP (qwen3.rs:323-327)
-        GemmPlan pg = plan_gemm(R, 2 * m->I_l, H, 8);
-        PROF(m, PROF_GEMM, launch_gemm(pg, m->xh, m->xl, H, w.gu, m->slabs, R, s));
-        PROF(m, PROF_SILU, launch_silu_mul(m->slabs, pg.n_split, (int64_t)R * 2 * m->I_l, R, m->I_l, m->xh, m->xl, nullptr, s));
+        // gate/up GEMM with the SiLU*mul epilogue: act hi/lo written directly, no slabs, no extra launch
+        GemmPlan pg = plan_gemm_swiglu(R, 2 * m->I_l, H);
+        PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, s));
         GemmPlan pd = plan_gemm(R, H, m->I_l, 8);
-        PROF(m, PROF_GEMM, launch_gemm(pd, m->xh, m->xl, m->I_l, w.down, m->slabs, R, s));
+        PROF(m, PROF_GEMM, launch_gemm(pd, m->xh2, m->xl2, m->I_l, w.down, m->slabs, R, s));
         rc = tp_reduce(m, R, pd.n_split, &prev, &prev_ns);
         if (rc) return rc;
         if (m->taps) {
@@ -761,7 +873,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         const int tp = ctx->tp_size;
         uint32_t* ids_dst = tp == 1 ? m->d_next + logits_row0 : m->d_next + m->cur_n + (size_t)ctx->tp_rank * m->cur_n + logits_row0;
         float* val_dst = tp == 1 ? nullptr : m->d_maxval + (size_t)ctx->tp_rank * m->cur_n + logits_row0;
-        HIPCHK(ctx, launch_argmax_parts(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, ids_dst, val_dst, s));
+        HIPCHK(ctx, launch_argmax_parts(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, m->argmax_scratch, ids_dst, val_dst, s));
     }
     return NVLLM_OK;
 }
@@ -809,8 +921,9 @@ static int finish_logits(nvllm_model* m, int n, uint32_t* next_ids, float* last_
     // local (max, idx) -> all-gather -> pick the best; ties go to the higher global index
     uint32_t* idx_all = m->d_next + n;           // [tp][n] lives after the first n entries
     float* val_all = m->d_maxval;                // [tp][n]
-    NCCLCHK(ctx, ncclAllGather(idx_all + (size_t)ctx->tp_rank * n, idx_all, n, ncclUint32, ctx->comm, s));
-    NCCLCHK(ctx, ncclAllGather(val_all + (size_t)ctx->tp_rank * n, val_all, n, ncclFloat, ctx->comm, s));
+    int rc_ = comm_allgather(ctx, idx_all + (size_t)ctx->tp_rank * n, idx_all, (size_t)n * 4);
+    if (!rc_) rc_ = comm_allgather(ctx, val_all + (size_t)ctx->tp_rank * n, val_all, (size_t)n * 4);
+    if (rc_) return rc_;
     std::vector<uint32_t> hi((size_t)tp * n);
     std::vector<float> hv((size_t)tp * n);
     HIPCHK(ctx, hipMemcpyAsync(hi.data(), idx_all, hi.size() * 4, hipMemcpyDeviceToHost, s));
@@ -833,11 +946,11 @@ static int finish_logits(nvllm_model* m, int n, uint32_t* next_ids, float* last_
         std::vector<float> shard((size_t)tp * n * Vl);
         float* dall = nullptr;
         HIPCHK(ctx, hipMalloc((void**)&dall, shard.size() * 4));
-        ncclResult_t r = ncclAllGather(m->logits, dall, (size_t)n * Vl, ncclFloat, ctx->comm, s);
-        hipError_t e = r == ncclSuccess ? hipMemcpyAsync(shard.data(), dall, shard.size() * 4, hipMemcpyDeviceToHost, s) : hipErrorUnknown;
+        int rg = comm_allgather(ctx, m->logits, dall, (size_t)n * Vl * 4);
+        hipError_t e = rg == 0 ? hipMemcpyAsync(shard.data(), dall, shard.size() * 4, hipMemcpyDeviceToHost, s) : hipSuccess;
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         (void)hipFree(dall);
-        if (r != ncclSuccess) return fail(ctx, NVLLM_ERCCL, "ncclAllGather(logits) -> %s", ncclGetErrorString(r));
+        if (rg) return rg;
         HIPCHK(ctx, e);
         for (int rk = 0; rk < tp; ++rk)
             for (int i = 0; i < n; ++i)
@@ -1085,7 +1198,7 @@ extern "C" int nvllm_op_pack_weight(nvllm_ctx* ctx, const void* host_w, int dtyp
     hipError_t e = hipMalloc((void**)&w->w.data, w->w.bytes());
     if (e == hipSuccess) e = hipMalloc((void**)&dtmp, tmp.size() * 2);
     if (e == hipSuccess) e = hipMemcpy(dtmp, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_pack_rows(w->w, 0, Np, dtmp, Kp, ctx->stream);
+    if (e == hipSuccess) e = launch_pack_rows(w->w, 0, Np, dtmp, Kp, -1, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (dtmp) (void)hipFree(dtmp);
     if (e != hipSuccess) { if (w->w.data) (void)hipFree(w->w.data); delete w; HIPCHK(ctx, e); }
@@ -1242,7 +1355,8 @@ extern "C" int nvllm_op_argmax(nvllm_ctx* ctx, const float* logits, int rows, in
 extern "C" int nvllm_op_allreduce(nvllm_ctx* ctx, float* buf, int64_t count) {
     if (!ctx || !buf || count < 0) return fail(ctx, NVLLM_EINVAL, "bad allreduce arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (ctx->tp_size > 1) NCCLCHK(ctx, ncclAllReduce(buf, buf, (size_t)count, ncclFloat, ncclSum, ctx->comm, ctx->stream));
+    int rc_ = comm_allreduce_sum(ctx, buf, (size_t)count);
+    if (rc_) return rc_;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return NVLLM_OK;
 }
@@ -1278,7 +1392,7 @@ extern "C" int nvllm_debug_gemm_bench(nvllm_ctx* ctx, int M, int N, int K, int n
     HIPCHK(ctx, t.get(&w.data, (size_t)N * K / 8));
     HIPCHK(ctx, t.get(&xh, (size_t)M * K)); HIPCHK(ctx, t.get(&xl, (size_t)M * K));
     HIPCHK(ctx, t.get(&out, (size_t)p.n_split * M * N));
-    HIPCHK(ctx, launch_synth_packed(w, 0, N, 12345, 0, 0, K, s));
+    HIPCHK(ctx, launch_synth_packed(w, 0, N, 12345, 0, 0, K, -1, s));
     HIPCHK(ctx, launch_synth_rowmajor_bf16(xh, 777, kSynthMatrix, 0, (int64_t)M * K, s));
     HIPCHK(ctx, launch_synth_rowmajor_bf16(xl, 778, kSynthMatrix, 0, (int64_t)M * K, s));
     for (int i = 0; i < 3; ++i) HIPCHK(ctx, launch_gemm(p, xh, xl, K, w, out, M, s));
@@ -1296,6 +1410,10 @@ extern "C" int nvllm_debug_gemm_bench(nvllm_ctx* ctx, int M, int N, int K, int n
 // sequence; part_tokens 0 = no split.  Returns microseconds per launch (attention + combine).
 extern "C" int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int hd, const int32_t* ctx_lens,
                                       int part_tokens, int iters, float* us_per_call) {
+    // NVLLM_ATTN_ROT = number of distinct cache copies cycled through (default 8: every launch reads cold HBM,
+    // like the model's per-layer caches); 1 = same buffers every launch (Infinity-Cache warm)
+    const char* rot_env = getenv("NVLLM_ATTN_ROT");
+    const int nrot = rot_env ? std::max(1, atoi(rot_env)) : 8;
     if (!ctx || !ctx_lens || !us_per_call || B < 1 || iters < 1 || (hd != 64 && hd != 128) || nh % kv)
         return fail(ctx, NVLLM_EINVAL, "bad attn_bench arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1313,14 +1431,18 @@ extern "C" int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int
     const size_t cache_elems = (size_t)nblk * kv * kBlockTokens * hd;
     float *q, *po, *pml; bf16_bits *oh, *ol;
     int *dbt, *dpos, *dslot, *dt0, *dtn, *dts;
-    HIPCHK(ctx, t.get(&kvl.k, cache_elems)); HIPCHK(ctx, t.get(&kvl.v, cache_elems));
+    std::vector<f16_bits*> rk(nrot), rv(nrot);
+    for (int r = 0; r < nrot; ++r) {
+        HIPCHK(ctx, t.get(&rk[r], cache_elems)); HIPCHK(ctx, t.get(&rv[r], cache_elems));
+        HIPCHK(ctx, launch_synth_rowmajor_bf16(rk[r], 1 + r, kSynthMatrix, 0, (int64_t)cache_elems, s));
+        HIPCHK(ctx, launch_synth_rowmajor_bf16(rv[r], 100 + r, kSynthMatrix, 0, (int64_t)cache_elems, s));
+    }
+    kvl.k = rk[0]; kvl.v = rv[0];
     HIPCHK(ctx, t.get(&q, (size_t)B * nh * hd)); HIPCHK(ctx, t.get(&oh, (size_t)B * nh * hd)); HIPCHK(ctx, t.get(&ol, (size_t)B * nh * hd));
     HIPCHK(ctx, t.get(&po, (size_t)B * nh * kAttnMaxParts * hd)); HIPCHK(ctx, t.get(&pml, (size_t)B * nh * kAttnMaxParts * 2));
     HIPCHK(ctx, t.get(&dbt, hbt.size())); HIPCHK(ctx, t.get(&dpos, B)); HIPCHK(ctx, t.get(&dslot, B));
     HIPCHK(ctx, t.get(&dt0, B)); HIPCHK(ctx, t.get(&dtn, B)); HIPCHK(ctx, t.get(&dts, B));
     // bf16-valued synthetic bits reinterpreted as f16 are small finite numbers: fine for timing
-    HIPCHK(ctx, launch_synth_rowmajor_bf16(kvl.k, 1, kSynthMatrix, 0, (int64_t)cache_elems, s));
-    HIPCHK(ctx, launch_synth_rowmajor_bf16(kvl.v, 2, kSynthMatrix, 0, (int64_t)cache_elems, s));
     HIPCHK(ctx, launch_synth_rowmajor_f32(q, 3, kSynthMatrix, 0, (int64_t)B * nh * hd, s));
     HIPCHK(ctx, hipMemcpyAsync(dbt, hbt.data(), hbt.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(dpos, hpos.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
@@ -1339,7 +1461,10 @@ extern "C" int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int
     }
     for (int i = 0; i < 3; ++i) HIPCHK(ctx, launch_attn_paged(a, B, 1, B, parts_max, s));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
-    for (int i = 0; i < iters; ++i) HIPCHK(ctx, launch_attn_paged(a, B, 1, B, parts_max, s));
+    for (int i = 0; i < iters; ++i) {
+        a.kv.k = rk[i % nrot]; a.kv.v = rv[i % nrot];
+        HIPCHK(ctx, launch_attn_paged(a, B, 1, B, parts_max, s));
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0;

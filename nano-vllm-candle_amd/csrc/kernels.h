@@ -21,11 +21,13 @@ struct PackedW {
 };
 
 // pack rows [row0, row0+rows) of dst from a row-major bf16 source (ld = elements between rows)
-hipError_t launch_pack_rows(const PackedW& dst, int row0, int rows, const bf16_bits* src, int64_t ld, hipStream_t s);
+// ileave: -1 = rows land at row0.. ; 0/1 = gate(0)/up(1) rows interleaved in 16-row tiles (SwiGLU epilogue layout)
+hipError_t launch_pack_rows(const PackedW& dst, int row0, int rows, const bf16_bits* src, int64_t ld, int ileave,
+                            hipStream_t s);
 // generate rows [row0,row0+rows) of dst from the synthetic tensor `name_hash`: logical element
 // (r, k) of the destination = source element (src_row0 + r, src_col0 + k) of a [*, src_ld] tensor
 hipError_t launch_synth_packed(const PackedW& dst, int row0, int rows, uint64_t name_hash, int64_t src_row0,
-                               int64_t src_col0, int64_t src_ld, hipStream_t s);
+                               int64_t src_col0, int64_t src_ld, int ileave, hipStream_t s);
 // row-major synthetic fill: dst bf16 [count] = elements [first, first+count)
 hipError_t launch_synth_rowmajor_bf16(bf16_bits* dst, uint64_t name_hash, int kind, int64_t first, int64_t count,
                                       hipStream_t s);
@@ -53,8 +55,13 @@ hipError_t launch_gemm(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* 
 hipError_t launch_gemm_argmax(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
                               float* out, int M, float* part_val, int* part_idx, hipStream_t s);
 int gemm_argmax_parts(const GemmPlan& p, int N);
-hipError_t launch_argmax_parts(const float* part_val, const int* part_idx, int n_parts, int M, uint32_t* ids,
-                               float* maxval, hipStream_t s);
+// gate/up projection with the SiLU*mul epilogue (weight interleaved by launch_pack_rows(..., ileave))
+GemmPlan plan_gemm_swiglu(int M, int N2, int K);
+hipError_t launch_gemm_swiglu(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
+                              int M, bf16_bits* act_hi, bf16_bits* act_lo, hipStream_t s);
+// scratch: 8*(M+1) bytes, zero before the first use (the kernel leaves it zero again)
+hipError_t launch_argmax_parts(const float* part_val, const int* part_idx, int n_parts, int M, void* scratch,
+                               uint32_t* ids, float* maxval, hipStream_t s);
 
 // ---- (embed +) add + RMSNorm ----------------------------------------------------------------------
 struct NormArgs {
@@ -115,6 +122,16 @@ struct AttnArgs {
     bf16_bits* out_hi = nullptr;       // [rows][nh_l*hd]
     bf16_bits* out_lo = nullptr;
     float* out_f32 = nullptr;          // optional f32 copy (fine-seam op)
+    // fused decode prologue (qkv != nullptr; every tile must be a single row): the kernel sums the QKV GEMM's
+    // slabs itself, applies q/k RMSNorm + RoPE, writes the row's K/V into the cache, then attends
+    const float* qkv = nullptr;        // [n_slabs][rows][ldqkv]
+    int n_slabs = 1, ldqkv = 0;
+    int64_t slab_stride = 0;
+    const float* qn = nullptr;
+    const float* kn = nullptr;
+    const float* cos = nullptr;
+    const float* sin = nullptr;
+    float eps = 1e-6f, q_scale = 1.f;
     // split-KV (decode): each workgroup covers part_tiles 32-token tiles; partials merged by a combine pass
     int part_tiles = 0, max_parts = 0;
     float* part_o = nullptr;           // [rows][nh_l][max_parts][hd]

@@ -5,6 +5,10 @@
 //   A frag: A[row l15][k = 8*grp + j]      B frag: B[k = 8*grp + j][col l15]      (j = 0..7)
 //   C/D   : D[row 4*grp + reg][col l15]    (reg = 0..3)
 #include "kernels.h"
+
+#include <algorithm>
+#include <cstdlib>
+
 #include "synth_device.h"
 
 namespace nvllm {
@@ -35,14 +39,20 @@ __device__ __forceinline__ float wave_sum(float v) {
 // weight packing / synthetic fill
 // ---------------------------------------------------------------------------------------------------
 // one thread per 16-byte lane slot of the destination: (dest row r, k-chunk of 8)
+// ileave >= 0: destination rows are interleaved in 16-row tiles, source row r -> ((r/16)*2 + ileave)*16 + r%16
+// (gate_up: tile 2t = gate features 16t.., tile 2t+1 = up features 16t.. so one wave holds both of a feature)
+__device__ __forceinline__ int dest_row(int row0, int rl, int ileave) {
+    return ileave < 0 ? row0 + rl : (((rl >> 4) * 2 + ileave) << 4) + (rl & 15);
+}
+
 __global__ void __launch_bounds__(256) pack_rows_kernel(uint4* __restrict__ dst, int KT, int row0, int rows,
-                                                        const uint16_t* __restrict__ src, int64_t ld) {
+                                                        const uint16_t* __restrict__ src, int64_t ld, int ileave) {
     const int64_t chunks_per_row = (int64_t)KT * 4;
     const int64_t total = (int64_t)rows * chunks_per_row;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int rl = (int)(i / chunks_per_row);
         const int kc8 = (int)(i % chunks_per_row);
-        const int r = row0 + rl;
+        const int r = dest_row(row0, rl, ileave);
         const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)rl * ld + (int64_t)kc8 * 8);
         const int nt = r >> 4, kt = kc8 >> 2, lane = ((kc8 & 3) << 4) | (r & 15);
         dst[((int64_t)nt * KT + kt) * 64 + lane] = v;
@@ -51,13 +61,13 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(uint4* __restrict__ dst,
 
 __global__ void __launch_bounds__(256) synth_packed_kernel(uint4* __restrict__ dst, int KT, int row0, int rows,
                                                            uint64_t name_hash, int64_t src_row0, int64_t src_col0,
-                                                           int64_t src_ld) {
+                                                           int64_t src_ld, int ileave) {
     const int64_t chunks_per_row = (int64_t)KT * 4;
     const int64_t total = (int64_t)rows * chunks_per_row;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int rl = (int)(i / chunks_per_row);
         const int kc8 = (int)(i % chunks_per_row);
-        const int r = row0 + rl;
+        const int r = dest_row(row0, rl, ileave);
         const uint64_t base = (uint64_t)(src_row0 + rl) * (uint64_t)src_ld + (uint64_t)(src_col0 + (int64_t)kc8 * 8);
         uint32_t w[4];
 #pragma unroll
@@ -89,16 +99,17 @@ static inline int grid_for(int64_t n, int per_block = 256, int cap = 8192) {
     return (int)g;
 }
 
-hipError_t launch_pack_rows(const PackedW& dst, int row0, int rows, const bf16_bits* src, int64_t ld, hipStream_t s) {
+hipError_t launch_pack_rows(const PackedW& dst, int row0, int rows, const bf16_bits* src, int64_t ld, int ileave,
+                            hipStream_t s) {
     const int KT = dst.K / 32;
-    pack_rows_kernel<<<grid_for((int64_t)rows * KT * 4), 256, 0, s>>>(dst.data, KT, row0, rows, src, ld);
+    pack_rows_kernel<<<grid_for((int64_t)rows * KT * 4), 256, 0, s>>>(dst.data, KT, row0, rows, src, ld, ileave);
     return hipGetLastError();
 }
 hipError_t launch_synth_packed(const PackedW& dst, int row0, int rows, uint64_t name_hash, int64_t src_row0,
-                               int64_t src_col0, int64_t src_ld, hipStream_t s) {
+                               int64_t src_col0, int64_t src_ld, int ileave, hipStream_t s) {
     const int KT = dst.K / 32;
     synth_packed_kernel<<<grid_for((int64_t)rows * KT * 4), 256, 0, s>>>(dst.data, KT, row0, rows, name_hash, src_row0,
-                                                                        src_col0, src_ld);
+                                                                        src_col0, src_ld, ileave);
     return hipGetLastError();
 }
 hipError_t launch_synth_rowmajor_bf16(bf16_bits* dst, uint64_t name_hash, int kind, int64_t first, int64_t count,
@@ -161,11 +172,14 @@ hipError_t launch_split_hilo(const float* x, bf16_bits* hi, bf16_bits* lo, int64
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int MT, int NT, int NW, int KC, bool ARGMAX>
+// MODE 0: f32 slabs.  MODE 1: + per-wave partial arg-max (LM head).  MODE 2: SwiGLU epilogue -- the weight is
+// the gate/up matrix interleaved in 16-row tiles (NT == 2: tile 0 = gate, tile 1 = up of the same 16 features),
+// the wave writes silu(gate)*up as bf16 hi/lo planes act[M][N/2] (SiluAndMul, activation.rs:13-18); no split-K.
+template <int MT, int NT, int NW, int KC, int MODE>
 __global__ void __launch_bounds__(NW * 64)
 gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, int ldx, const uint4* __restrict__ wp,
             float* __restrict__ out, int M, int N, int KT, int kt_per_split, float* __restrict__ part_val,
-            int* __restrict__ part_idx) {
+            int* __restrict__ part_idx, uint16_t* __restrict__ act_hi, uint16_t* __restrict__ act_lo) {
     // LDS: two buffers of [2 planes][MT][KC][64 lanes] 16-byte slots, filled by LDS-DMA (global_load_lds):
     // the image is lane-linear per fragment, so every wave-DMA writes one contiguous 1 KiB and every
     // ds_read_b128 of a fragment is conflict-free.
@@ -238,26 +252,29 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
         }
     };
 
-    // Two chunks are issued up front (both LDS buffers, both register sets): a K-slice of <= 2 chunks --
-    // every decode-shape split -- costs ONE memory round trip instead of two dependent ones.
-    if (nchunks > 0) issue(0, 0, wf0);
-    if (nchunks > 1) issue(1, 1, wf1);
-    for (int c = 0; c < nchunks; c += 2) {
-        __syncthreads();  // vmcnt(0) + barrier: everything issued so far has landed
-        compute(0, wf0);
-        if (c + 2 < nchunks) {
-            __syncthreads();  // WAR: every wave is done reading buffer 0
-            issue(c + 2, 0, wf0);
-        }
-        if (c + 1 >= nchunks) break;
-        compute(1, wf1);  // chunk c+1 landed before the barrier at the top of this iteration
-        if (c + 3 < nchunks) {
+    if (nchunks <= 2) {
+        // Both chunks are issued up front (both LDS buffers, both register sets): a K-slice of <= 2 chunks --
+        // every decode-shape split -- costs ONE memory round trip instead of two dependent ones.
+        if (nchunks > 0) issue(0, 0, wf0);
+        if (nchunks > 1) issue(1, 1, wf1);
+        __syncthreads();  // vmcnt(0) + barrier: everything has landed
+        if (nchunks > 0) compute(0, wf0);
+        if (nchunks > 1) compute(1, wf1);
+    } else {
+        // long K (LM head, prefill): one chunk ahead, one barrier per chunk
+        issue(0, 0, wf0);
+        for (int c = 0; c < nchunks; c += 2) {
+            __syncthreads();  // chunk c has landed; buffer 1 is free again
+            if (c + 1 < nchunks) issue(c + 1, 1, wf1);
+            compute(0, wf0);
+            if (c + 1 >= nchunks) break;
             __syncthreads();
-            issue(c + 3, 1, wf1);
+            if (c + 2 < nchunks) issue(c + 2, 0, wf0);
+            compute(1, wf1);
         }
     }
     // D[feature 4*grp+reg][token l15] -> out[token][feature..feature+3]
-    if (out) {
+    if (MODE != 2 && out) {
         float* o = out + (size_t)blockIdx.y * (size_t)M * N;
 #pragma unroll
         for (int a = 0; a < NT; ++a) {
@@ -273,7 +290,28 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
             }
         }
     }
-    if constexpr (ARGMAX) {
+    if constexpr (MODE == 2) {
+        static_assert(MODE != 2 || NT == 2, "SwiGLU epilogue needs the gate and the up tile in one wave");
+        const int I = N >> 1;
+        if (nt0 < ntiles) {
+            const int f0 = (nt0 >> 1) * 16 + grp * 4;  // activation feature of acc[.][.][0]
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const int row = m0 + b * 16 + l15;
+                if (row < M) {
+                    uint16_t h[4], l[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float g = acc[0][b][r], u = acc[NT - 1][b][r];
+                        split_bf16((g / (1.0f + __expf(-g))) * u, h[r], l[r]);
+                    }
+                    *reinterpret_cast<uint2*>(act_hi + (size_t)row * I + f0) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+                    *reinterpret_cast<uint2*>(act_lo + (size_t)row * I + f0) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+                }
+            }
+        }
+    }
+    if constexpr (MODE == 1) {
         // per-wave partial argmax over its NT*16 features (greedy LM head): LAST max wins
         // (llm_engine.rs:135-142).  part_*[wave_global][row]; finished by argmax_parts_kernel.
         const int wg = blockIdx.x * NW + wave;
@@ -306,33 +344,58 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
     }
 }
 
-// finish the fused LM-head argmax: one workgroup per row over n_parts partials
+// finish the fused LM-head arg-max.  part_*[p][row] (row fastest): thread = (row%64, plane); a block scans one
+// slice of the partials with coalesced loads, reduces its 4 planes in LDS and folds its result into a per-row
+// 64-bit key {order-preserving float bits, index} with one atomicMax per row; the last block to finish decodes
+// the keys into ids / max values and re-arms the scratch words (keys and ticket are zero between launches).
+__device__ __forceinline__ unsigned long long argmax_key(float v, int idx) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned)idx;
+}
 __global__ void __launch_bounds__(256) argmax_parts_kernel(const float* __restrict__ part_val,
                                                            const int* __restrict__ part_idx, int n_parts, int M,
-                                                           uint32_t* __restrict__ ids, float* __restrict__ maxval) {
-    __shared__ float sv[4];
-    __shared__ int si[4];
-    const int row = blockIdx.x;
-    float bv = -INFINITY;
-    int bi = -1;
-    for (int p = threadIdx.x; p < n_parts; p += blockDim.x) {
-        const float v = part_val[(size_t)p * M + row];
-        const int i = part_idx[(size_t)p * M + row];
-        if (i >= 0 && (bi < 0 || v > bv || (v == bv && i > bi))) { bv = v; bi = i; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o);
-        const int oi = __shfl_xor(bi, o);
-        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
-    }
-    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+                                                           unsigned long long* __restrict__ keys,
+                                                           unsigned* __restrict__ ticket, uint32_t* __restrict__ ids,
+                                                           float* __restrict__ maxval) {
+    __shared__ unsigned long long sk[256];
+    __shared__ unsigned last;
+    const int r = threadIdx.x & 63, plane = threadIdx.x >> 6;
+    const int row = blockIdx.y * 64 + r;
+    const int per = (n_parts + gridDim.x - 1) / gridDim.x;
+    const int p0 = blockIdx.x * per, p1 = min(n_parts, p0 + per);
+    unsigned long long best = 0;
+    if (row < M)
+        for (int p = p0 + plane; p < p1; p += 4) {
+            const int i = part_idx[(size_t)p * M + row];
+            if (i >= 0) {
+                const unsigned long long k = argmax_key(part_val[(size_t)p * M + row], i);
+                best = k > best ? k : best;
+            }
+        }
+    sk[threadIdx.x] = best;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (si[w] >= 0 && (bi < 0 || sv[w] > bv || (sv[w] == bv && si[w] > bi))) { bv = sv[w]; bi = si[w]; }
-        ids[row] = (uint32_t)(bi < 0 ? 0 : bi);
-        if (maxval) maxval[row] = bv;
+    if (plane == 0 && row < M) {
+        for (int q = 1; q < 4; ++q) best = sk[q * 64 + r] > best ? sk[q * 64 + r] : best;
+        if (best) atomicMax(&keys[row], best);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
+    __syncthreads();
+    if (last) {
+        __threadfence();
+        for (int i = threadIdx.x; i < M; i += blockDim.x) {
+            const unsigned long long k = __hip_atomic_load(&keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ids[i] = (uint32_t)(k & 0xffffffffu);
+            if (maxval) {
+                unsigned u = (unsigned)(k >> 32);
+                u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+                maxval[i] = __builtin_bit_cast(float, u);
+            }
+            keys[i] = 0;
+        }
+        if (threadIdx.x == 0) *ticket = 0;
     }
 }
 
@@ -360,63 +423,99 @@ GemmPlan plan_gemm(int M, int N, int K, int max_split) {
     return p;
 }
 
-template <int MT, int NT, int NW, int KC, bool ARGMAX>
+struct GemmExtra {
+    float* part_val = nullptr;   // MODE 1
+    int* part_idx = nullptr;
+    bf16_bits* act_hi = nullptr; // MODE 2
+    bf16_bits* act_lo = nullptr;
+};
+
+template <int MT, int NT, int NW, int KC, int MODE>
 static hipError_t gemm_launch_t(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
-                                float* out, int M, float* part_val, int* part_idx, hipStream_t s) {
+                                float* out, int M, const GemmExtra& x, hipStream_t s) {
     const int ntiles = w.N / 16;
     dim3 grid((ntiles + NT * NW - 1) / (NT * NW), p.n_split, (M + MT * 16 - 1) / (MT * 16));
     const size_t lds = (size_t)2 * 2 * MT * KC * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<MT, NT, NW, KC, ARGMAX>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<MT, NT, NW, KC, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    gemm_kernel<MT, NT, NW, KC, ARGMAX><<<grid, NW * 64, lds, s>>>(xh, xl, ldx, w.data, out, M, w.N, w.K / 32,
-                                                                  p.kt_per_split, part_val, part_idx);
+    gemm_kernel<MT, NT, NW, KC, MODE><<<grid, NW * 64, lds, s>>>(xh, xl, ldx, w.data, out, M, w.N, w.K / 32, p.kt_per_split,
+                                                                x.part_val, x.part_idx, x.act_hi, x.act_lo);
     return hipGetLastError();
 }
 
-template <int NW>
+template <int NW, int MODE>
 static hipError_t gemm_dispatch_nw(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
-                                   float* out, int M, float* part_val, int* part_idx, hipStream_t s) {
-#define NVLLM_GEMM_CASE(MT_, NT_, KC_)                                                                              \
-    if (p.mt == MT_ && p.nt == NT_ && p.kc == KC_) {                                                                 \
-        if (part_val) return gemm_launch_t<MT_, NT_, NW, KC_, true>(p, xh, xl, ldx, w, out, M, part_val, part_idx, s); \
-        return gemm_launch_t<MT_, NT_, NW, KC_, false>(p, xh, xl, ldx, w, out, M, nullptr, nullptr, s);               \
+                                   float* out, int M, const GemmExtra& x, hipStream_t s) {
+#define NVLLM_GEMM_CASE(MT_, NT_, KC_) \
+    if (p.mt == MT_ && p.nt == NT_ && p.kc == KC_) return gemm_launch_t<MT_, NT_, NW, KC_, MODE>(p, xh, xl, ldx, w, out, M, x, s);
+    if constexpr (MODE != 2) {
+        NVLLM_GEMM_CASE(1, 1, 4)
+        NVLLM_GEMM_CASE(2, 1, 4)
+        NVLLM_GEMM_CASE(4, 1, 4)
+        NVLLM_GEMM_CASE(8, 1, 2)
     }
-    NVLLM_GEMM_CASE(1, 1, 4)
     NVLLM_GEMM_CASE(1, 2, 4)
-    NVLLM_GEMM_CASE(2, 1, 4)
     NVLLM_GEMM_CASE(2, 2, 4)
-    NVLLM_GEMM_CASE(4, 1, 4)
     NVLLM_GEMM_CASE(4, 2, 4)
-    NVLLM_GEMM_CASE(8, 1, 2)
     NVLLM_GEMM_CASE(8, 2, 2)
 #undef NVLLM_GEMM_CASE
     return hipErrorInvalidValue;
 }
 
+template <int MODE>
+static hipError_t gemm_dispatch(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
+                                float* out, int M, const GemmExtra& x, hipStream_t s) {
+    if ((w.K / 32) % p.kc != 0 || p.kt_per_split % p.kc != 0) return hipErrorInvalidValue;
+    if (p.nw == 2) return gemm_dispatch_nw<2, MODE>(p, xh, xl, ldx, w, out, M, x, s);
+    if (p.nw == 4) return gemm_dispatch_nw<4, MODE>(p, xh, xl, ldx, w, out, M, x, s);
+    if (p.nw == 8) return gemm_dispatch_nw<8, MODE>(p, xh, xl, ldx, w, out, M, x, s);
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_gemm(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
                        float* out, int M, hipStream_t s) {
-    return launch_gemm_argmax(p, xh, xl, ldx, w, out, M, nullptr, nullptr, s);
+    return gemm_dispatch<0>(p, xh, xl, ldx, w, out, M, GemmExtra{}, s);
 }
 
 hipError_t launch_gemm_argmax(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
                               float* out, int M, float* part_val, int* part_idx, hipStream_t s) {
-    if (part_val && p.n_split != 1) return hipErrorInvalidValue;
-    if ((w.K / 32) % p.kc != 0 || p.kt_per_split % p.kc != 0) return hipErrorInvalidValue;
-    if (p.nw == 2) return gemm_dispatch_nw<2>(p, xh, xl, ldx, w, out, M, part_val, part_idx, s);
-    if (p.nw == 4) return gemm_dispatch_nw<4>(p, xh, xl, ldx, w, out, M, part_val, part_idx, s);
-    if (p.nw == 8) return gemm_dispatch_nw<8>(p, xh, xl, ldx, w, out, M, part_val, part_idx, s);
-    return hipErrorInvalidValue;
+    if (!part_val || !part_idx || p.n_split != 1) return hipErrorInvalidValue;
+    GemmExtra x;
+    x.part_val = part_val; x.part_idx = part_idx;
+    return gemm_dispatch<1>(p, xh, xl, ldx, w, out, M, x, s);
 }
+
+// gate/up GEMM with the SwiGLU epilogue; w = interleaved gate_up [2I][K]; act planes [M][I]
+hipError_t launch_gemm_swiglu(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
+                              int M, bf16_bits* act_hi, bf16_bits* act_lo, hipStream_t s) {
+    if (p.nt != 2 || p.n_split != 1 || !act_hi || !act_lo) return hipErrorInvalidValue;
+    GemmExtra x;
+    x.act_hi = act_hi; x.act_lo = act_lo;
+    return gemm_dispatch<2>(p, xh, xl, ldx, w, nullptr, M, x, s);
+}
+GemmPlan plan_gemm_swiglu(int M, int N2, int K) {
+    GemmPlan p = plan_gemm(M, N2, K, 1);
+    p.nt = 2;
+    // few rows: many small workgroups (each wave streams its own two tiles); many rows: share x across 4 waves
+    p.nw = M <= 128 ? 2 : 4;
+    set_split(p, K / 32, 1);
+    return p;
+}
+
 int gemm_argmax_parts(const GemmPlan& p, int N) { return ((N / 16 + p.nt * p.nw - 1) / (p.nt * p.nw)) * p.nw; }
 
-hipError_t launch_argmax_parts(const float* part_val, const int* part_idx, int n_parts, int M, uint32_t* ids,
-                               float* maxval, hipStream_t s) {
+hipError_t launch_argmax_parts(const float* part_val, const int* part_idx, int n_parts, int M, void* scratch,
+                               uint32_t* ids, float* maxval, hipStream_t s) {
     if (M <= 0) return hipSuccess;
-    argmax_parts_kernel<<<M, 256, 0, s>>>(part_val, part_idx, n_parts, M, ids, maxval);
+    // scratch: [0] ticket (u32, padded to 8 B), then M u64 keys; zeroed once at allocation, re-armed by the kernel
+    unsigned* ticket = reinterpret_cast<unsigned*>(scratch);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(scratch) + 1;
+    dim3 grid(std::max(1, std::min(64, n_parts / 64)), (M + 63) / 64);
+    argmax_parts_kernel<<<grid, 256, 0, s>>>(part_val, part_idx, n_parts, M, keys, ticket, ids, maxval);
     return hipGetLastError();
 }
 
@@ -612,7 +711,7 @@ hipError_t launch_kv_write_plain(const float* k, const float* v, int rows, const
 //                                                          from the S accumulators (no lane movement)
 // Both products keep the q row on lane&15, so the online-softmax state (m, l) is per-lane.
 // ---------------------------------------------------------------------------------------------------
-template <int HD, int QT, int NWV>
+template <int HD, int QT, int NWV, bool FUSED>
 __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
     constexpr int DC = HD / 32, DT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -645,36 +744,6 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
     const int t_end = a.part_tiles ? min(n_kv_tiles, t_begin + a.part_tiles) : n_kv_tiles;
     if (t_begin >= n_kv_tiles) return;  // uniform for the whole workgroup
 
-    f16x8 qh[QT][DC], ql[QT][DC];
-#pragma unroll
-    for (int t = 0; t < QT; ++t)
-#pragma unroll
-        for (int c = 0; c < DC; ++c) {
-            float x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (my_row[t] >= 0) {
-                const float4* p =
-                    reinterpret_cast<const float4*>(a.q + (size_t)my_row[t] * ldq + (size_t)my_head * HD + c * 32 + grp * 8);
-                const float4 u = p[0], w = p[1];
-                x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = w.x; x[5] = w.y; x[6] = w.z; x[7] = w.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const _Float16 h = (_Float16)x[j];
-                qh[t][c][j] = h;
-                ql[t][c][j] = (_Float16)(x[j] - (float)h);
-            }
-        }
-
-    f32x4 o[QT][DT];
-    float m[QT], lsum[QT];
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        m[t] = -1e30f;
-        lsum[t] = 0.f;
-#pragma unroll
-        for (int d = 0; d < DT; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
     const int* bt = a.block_tables + (size_t)slot * a.max_blocks;
     const _Float16* kbase = reinterpret_cast<const _Float16*>(a.kv.k);
     const _Float16* vbase = reinterpret_cast<const _Float16*>(a.kv.v);
@@ -694,6 +763,143 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
 #pragma unroll
         for (int d = 0; d < DT; ++d) vf[d] = *reinterpret_cast<const uint4*>(vb + d * 512 + lane * 8);
     };
+    // decode register sets (QT == 1); set A may be prefetched before the fused prologue
+    uint4 kaA[DC], kbA[DC], vfA[DT], kaB[DC], kbB[DC], vfB[DT];
+    bool pre_loaded = false;
+    if constexpr (FUSED) {
+        // start this wave's first tile before the prologue unless it is the tile the new token goes into
+        // (that one must be read after wave 0 has written it)
+        const int kt0 = min(t_begin + wave, t_end - 1);
+        if (kt0 != (pmax >> 5)) {
+            load_tile(kt0, kaA, kbA, vfA);
+            pre_loaded = true;
+        }
+    }
+    f16x8 qh[QT][DC], ql[QT][DC];
+    if constexpr (FUSED) {
+        // Decode, fused prologue (replaces a separate launch): this workgroup is the only consumer of q heads
+        // kh*gqa.. of its row and the only producer of that row's K/V for kv head kh.  The QKV GEMM's split-K
+        // slabs are summed here; q/k get RMSNorm over head_dim then RoPE (qwen3.rs:224-234) exactly as
+        // qk_norm_rope_kvwrite_kernel does for prefill.
+        static_assert(QT == 1, "fused prologue is for single-row (decode) tiles");
+        constexpr int half = HD / 2;
+        const int row = row0;
+        const int pos = a.pos[row];
+        const float* qkv_row = a.qkv + (size_t)row * a.ldqkv;
+        const bool owner = (pos >> 5) >= t_begin && (pos >> 5) < t_end;  // split-KV: one workgroup writes K/V
+        if (wave == 0 && owner) {
+            const bool act = lane < half;
+            const int blk = bt[pos >> 8];
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {  // 0: k head, 1: v head
+                const float* p = qkv_row + (size_t)(a.nh_l + which * kv_l + kh) * HD;
+                float x1 = 0.f, x2 = 0.f;
+                if (act) {
+                    x1 = p[lane];
+                    x2 = p[lane + half];
+                    for (int sl = 1; sl < a.n_slabs; ++sl) {
+                        x1 += p[(size_t)sl * a.slab_stride + lane];
+                        x2 += p[(size_t)sl * a.slab_stride + lane + half];
+                    }
+                }
+                if (which == 0) {
+                    const float ss = wave_sum(x1 * x1 + x2 * x2);
+                    const float rinv = 1.0f / sqrtf(ss / (float)HD + a.eps);
+                    if (act) {
+                        const float n1 = (x1 * rinv) * a.kn[lane], n2 = (x2 * rinv) * a.kn[lane + half];
+                        const float c = a.cos[(size_t)pos * half + lane], sn = a.sin[(size_t)pos * half + lane];
+                        _Float16* k = reinterpret_cast<_Float16*>(a.kv.k) + (size_t)(blk * kv_l + kh) * kBlockTokens * HD;
+                        k[k_packed_offset(pos & 255, lane, HD)] = f16_sat(n1 * c - n2 * sn);
+                        k[k_packed_offset(pos & 255, lane + half, HD)] = f16_sat(n2 * c + n1 * sn);
+                    }
+                } else if (act) {
+                    _Float16* v = reinterpret_cast<_Float16*>(a.kv.v) + (size_t)(blk * kv_l + kh) * kBlockTokens * HD;
+                    v[v_packed_offset(pos & 255, lane, HD)] = f16_sat(x1);
+                    v[v_packed_offset(pos & 255, lane + half, HD)] = f16_sat(x2);
+                }
+            }
+            // make the new token visible to the other waves of THIS workgroup (same CU: write-through L1 -> L2)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        // q rows of this lane: dims c*32 + grp*8 + j; RoPE pairs chunk c with c + DC/2 (same lane)
+        float x[DC][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[c][j] = 0.f;
+            if (my_row[0] >= 0) {
+                const float* p = qkv_row + (size_t)my_head * HD + c * 32 + grp * 8;
+                for (int sl = 0; sl < a.n_slabs; ++sl) {
+                    const float4 u = *reinterpret_cast<const float4*>(p + (size_t)sl * a.slab_stride);
+                    const float4 w = *reinterpret_cast<const float4*>(p + (size_t)sl * a.slab_stride + 4);
+                    x[c][0] += u.x; x[c][1] += u.y; x[c][2] += u.z; x[c][3] += u.w;
+                    x[c][4] += w.x; x[c][5] += w.y; x[c][6] += w.z; x[c][7] += w.w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += x[c][j] * x[c][j];
+        }
+        ss += __shfl_xor(ss, 16);
+        ss += __shfl_xor(ss, 32);
+        const float rinv = 1.0f / sqrtf(ss / (float)HD + a.eps);
+#pragma unroll
+        for (int c = 0; c < DC / 2; ++c) {
+            float cs[8], sn[8], w1[8], w2[8];
+            const int d0 = c * 32 + grp * 8;  // index inside the half
+            *reinterpret_cast<float4*>(cs) = *reinterpret_cast<const float4*>(a.cos + (size_t)pos * half + d0);
+            *reinterpret_cast<float4*>(cs + 4) = *reinterpret_cast<const float4*>(a.cos + (size_t)pos * half + d0 + 4);
+            *reinterpret_cast<float4*>(sn) = *reinterpret_cast<const float4*>(a.sin + (size_t)pos * half + d0);
+            *reinterpret_cast<float4*>(sn + 4) = *reinterpret_cast<const float4*>(a.sin + (size_t)pos * half + d0 + 4);
+            *reinterpret_cast<float4*>(w1) = *reinterpret_cast<const float4*>(a.qn + d0);
+            *reinterpret_cast<float4*>(w1 + 4) = *reinterpret_cast<const float4*>(a.qn + d0 + 4);
+            *reinterpret_cast<float4*>(w2) = *reinterpret_cast<const float4*>(a.qn + half + d0);
+            *reinterpret_cast<float4*>(w2 + 4) = *reinterpret_cast<const float4*>(a.qn + half + d0 + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float n1 = (x[c][j] * rinv) * w1[j], n2 = (x[c + DC / 2][j] * rinv) * w2[j];
+                const float y1 = (n1 * cs[j] - n2 * sn[j]) * a.q_scale;
+                const float y2 = (n2 * cs[j] + n1 * sn[j]) * a.q_scale;
+                const _Float16 h1 = (_Float16)y1, h2 = (_Float16)y2;
+                qh[0][c][j] = h1;
+                ql[0][c][j] = (_Float16)(y1 - (float)h1);
+                qh[0][c + DC / 2][j] = h2;
+                ql[0][c + DC / 2][j] = (_Float16)(y2 - (float)h2);
+            }
+        }
+        __syncthreads();  // the new token's K/V (written by wave 0 above) is visible from here on
+    } else {
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int c = 0; c < DC; ++c) {
+                float x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (my_row[t] >= 0) {
+                    const float4* p = reinterpret_cast<const float4*>(a.q + (size_t)my_row[t] * ldq + (size_t)my_head * HD +
+                                                                      c * 32 + grp * 8);
+                    const float4 u = p[0], w = p[1];
+                    x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = w.x; x[5] = w.y; x[6] = w.z; x[7] = w.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const _Float16 h = (_Float16)x[j];
+                    qh[t][c][j] = h;
+                    ql[t][c][j] = (_Float16)(x[j] - (float)h);
+                }
+            }
+    }
+
+    f32x4 o[QT][DT];
+    float m[QT], lsum[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m[t] = -1e30f;
+        lsum[t] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
     auto compute_tile = [&](int kt, const uint4 (&ka)[DC], const uint4 (&kb2)[DC], const uint4 (&vf)[DT]) {
         const int T0 = kt << 5;
         const int tokA = T0 + grp * 4, tokB = T0 + 16 + grp * 4;
@@ -745,9 +951,8 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
         if constexpr (QT == 1) {
             // decode: two named register sets; the next tile's 16 KiB are in flight while this one is consumed.
             // Prefetches are unconditional (tile index clamped): no branch around loads.
-            uint4 kaA[DC], kbA[DC], vfA[DT], kaB[DC], kbB[DC], vfB[DT];
             int kt = t_begin + wave;
-            load_tile(min(kt, t_end - 1), kaA, kbA, vfA);
+            if (!pre_loaded) load_tile(min(kt, t_end - 1), kaA, kbA, vfA);
             while (kt < t_end) {
                 load_tile(min(kt + NWV, t_end - 1), kaB, kbB, vfB);
                 compute_tile(kt, kaA, kbA, vfA);
@@ -882,18 +1087,18 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(AttnArgs a, int rows)
     }
 }
 
-template <int HD, int QT, int NWV>
+template <int HD, int QT, int NWV, bool FUSED>
 static hipError_t attn_launch_t(const AttnArgs& a, int n_tiles, int grid_z, hipStream_t s) {
     constexpr int DT = HD / 16;
     const size_t lds = (size_t)NWV * QT * 2 * 16 * 4 + (size_t)NWV * QT * DT * 64 * 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_paged_kernel<HD, QT, NWV>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_paged_kernel<HD, QT, NWV, FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(n_tiles, a.kv.kv_l, grid_z);
-    attn_paged_kernel<HD, QT, NWV><<<grid, NWV * 64, lds, s>>>(a);
+    attn_paged_kernel<HD, QT, NWV, FUSED><<<grid, NWV * 64, lds, s>>>(a);
     return hipGetLastError();
 }
 
@@ -907,10 +1112,14 @@ hipError_t launch_attn_paged(const AttnArgs& a, int n_tiles, int qt, int rows, i
     if (!split) b.part_tiles = 0;
     const int gz = split ? n_parts_max : 1;
     hipError_t e = hipErrorInvalidValue;
-    if (a.kv.hd == 128 && qt == 1) e = attn_launch_t<128, 1, 4>(b, n_tiles, gz, s);
-    else if (a.kv.hd == 128 && qt == 2) e = attn_launch_t<128, 2, 4>(b, n_tiles, gz, s);
-    else if (a.kv.hd == 64 && qt == 1) e = attn_launch_t<64, 1, 4>(b, n_tiles, gz, s);
-    else if (a.kv.hd == 64 && qt == 2) e = attn_launch_t<64, 2, 4>(b, n_tiles, gz, s);
+    const bool fused = a.qkv != nullptr;  // decode rows straight from the QKV GEMM's slabs
+    if (fused && qt != 1) return hipErrorInvalidValue;
+    static const int decode_waves = [] { const char* e = getenv("NVLLM_ATTN_WAVES"); return e ? atoi(e) : 4; }();
+    if (a.kv.hd == 128 && qt == 1 && decode_waves == 8) e = fused ? attn_launch_t<128, 1, 8, true>(b, n_tiles, gz, s) : attn_launch_t<128, 1, 8, false>(b, n_tiles, gz, s);
+    else if (a.kv.hd == 128 && qt == 1) e = fused ? attn_launch_t<128, 1, 4, true>(b, n_tiles, gz, s) : attn_launch_t<128, 1, 4, false>(b, n_tiles, gz, s);
+    else if (a.kv.hd == 128 && qt == 2) e = attn_launch_t<128, 2, 4, false>(b, n_tiles, gz, s);
+    else if (a.kv.hd == 64 && qt == 1) e = fused ? attn_launch_t<64, 1, 4, true>(b, n_tiles, gz, s) : attn_launch_t<64, 1, 4, false>(b, n_tiles, gz, s);
+    else if (a.kv.hd == 64 && qt == 2) e = attn_launch_t<64, 2, 4, false>(b, n_tiles, gz, s);
     if (e != hipSuccess || !split) return e;
     const int items = rows * a.nh_l;
     if (a.kv.hd == 128) attn_combine_kernel<128><<<(items + 3) / 4, 256, 0, s>>>(b, rows);

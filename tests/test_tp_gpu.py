@@ -1,0 +1,72 @@
+"""GPU: the tensor-parallel code path end to end on ONE GPU through the in-process loopback communicator
+(one host thread per rank): sharded synthetic load, per-rank kernels on kv-head / MLP-column / vocab shards,
+the two all-reduces per layer, vocab-parallel greedy ids and logits gather.  Oracle for TP=N is TP=1 (the
+reference has no working TP): logits within tolerance (the order of the sum differs), ids equal."""
+import threading
+
+import numpy as np
+import pytest
+
+from tests.util import LOGITS_TOL, oracle_config, row_rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_tp(pkg, cfg, tp, seqs, steps, group):
+    results = [None] * tp
+    errors = []
+
+    def worker(rank):
+        try:
+            ctx = pkg.Context(0, tp_rank=rank, tp_size=tp, loopback_group=group)
+            m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=4, ctx=ctx)
+            m.kv_alloc(8, 4, 40)
+            my = [list(s) for s in seqs]
+            out = []
+            for step in range(steps):
+                ids, lg = m.step(list(range(len(my))), my, step == 0, want_logits=True)
+                out.append((ids.copy(), lg.copy()))
+                for s, t in zip(my, ids):
+                    s.append(int(t))
+            nxt = m.decode_next()[:len(my)].copy()  # device-feedback path under TP
+            results[rank] = (out, nxt)
+            m.close()
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(tp)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(r is not None for r in results), "a rank hung"
+    return results
+
+
+@pytest.mark.parametrize("tp,kw", [(2, dict()),
+                                   (4, dict(hidden_size=256, num_attention_heads=8, num_key_value_heads=4, head_dim=64,
+                                            intermediate_size=512, num_hidden_layers=3, vocab_size=1024))])
+def test_tp_equals_tp1(tp, kw, oracle):
+    import nano_vllm_candle_amd as pkg
+
+    cfg = pkg.Qwen3Config.tiny(**kw)
+    rng = np.random.default_rng(8)
+    seqs = [rng.integers(0, cfg.vocab_size, n).tolist() for n in (13, 50, 3)]  # 50 > 40: chunked prefill
+    steps = 5
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(4)
+    res = _run_tp(pkg, cfg, tp, seqs, steps, f"g{tp}")
+    ref_seqs = [list(s) for s in seqs]
+    for step in range(steps):
+        rid, rlg = om.run_greedy(ref_seqs)
+        for rank in range(tp):
+            ids, lg = res[rank][0][step]
+            assert row_rel_err(lg, rlg) < LOGITS_TOL, (rank, step)
+            assert ids.tolist() == rid.tolist(), (rank, step)
+            assert np.array_equal(lg, res[0][0][step][1])  # every rank returns the same gathered logits
+        for s, t in zip(ref_seqs, rid):
+            s.append(int(t))
+    rid, _ = om.run_greedy(ref_seqs)
+    for rank in range(tp):
+        assert res[rank][1].tolist() == rid.tolist()

@@ -1,4 +1,5 @@
-"""Time the decode attention kernel alone for several context-length distributions / split sizes."""
+"""Time the decode attention kernel alone for several context-length distributions / split sizes.
+NVLLM_ATTN_ROT=n cycles n cache copies (default 8: cold HBM every launch); NVLLM_ATTN_WAVES=4|8."""
 import ctypes as C
 import os
 import sys
@@ -12,7 +13,7 @@ ctx = pkg.Context(0)
 L = pkg._lib.lib()
 
 
-def run(lens, part, nh=16, kv=8, hd=128, iters=30):
+def run(lens, part, nh=16, kv=8, hd=128, iters=40):
     lens = np.ascontiguousarray(lens, np.int32)
     us = C.c_float()
     rc = L.nvllm_debug_attn_bench(ctx.h, len(lens), nh, kv, hd, lens.ctypes.data_as(C.POINTER(C.c_int32)), part, iters, C.byref(us))
@@ -25,10 +26,10 @@ def run(lens, part, nh=16, kv=8, hd=128, iters=30):
 rng = np.random.default_rng(0)
 bench_lens = rng.integers(64, 513, 64) + 20
 cases = {"bench U[64,512]+20": bench_lens, "uniform 333": np.full(64, 333), "uniform 512": np.full(64, 512),
-         "uniform 128": np.full(64, 128), "uniform 2048": np.full(64, 2048), "B=1 ctx 4096": np.full(1, 4096),
-         "B=8 ctx 1024": np.full(8, 1024), "B=256 ctx 512": np.full(256, 512)}
+         "B=1 ctx 4096": np.full(1, 4096), "B=8 ctx 1024": np.full(8, 1024)}
+parts = [int(p) for p in os.environ.get("PARTS", "0,256").split(",")]
 for name, lens in cases.items():
-    for part in (0, 128, 256, 512):
+    for part in parts:
         r = run(lens, part)
         if r:
-            print(f"{name:22s} part={part:4d}: {r[0]:8.2f} us  {r[1]:7.1f} GB/s", flush=True)
+            print(f"waves={os.environ.get('NVLLM_ATTN_WAVES','4')} rot={os.environ.get('NVLLM_ATTN_ROT','8')} {name:22s} part={part:4d}: {r[0]:8.2f} us  {r[1]:7.1f} GB/s", flush=True)
