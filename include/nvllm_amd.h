@@ -195,6 +195,11 @@ int nvllm_op_synth_bf16(nvllm_ctx* ctx, const char* name, uint64_t seed, int kin
 int nvllm_debug_gemm_bench(nvllm_ctx* ctx, int M, int N, int K, int nt, int nw, int n_split, int iters,
                            float* us_per_call);
 
+/* tuning aid v2: explicit m-tiles per workgroup, epilogue mode (0 slabs, 2 SwiGLU with N = 2I) and `rot` weight
+ * copies cycled per launch (cold HBM like the model; 1 = cache-warm) */
+int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int mt, int nt, int nw, int n_split, int mode, int rot,
+                            int iters, float* us_per_call);
+
 /* tuning aid: time the decode attention (one new token per sequence, ctx_lens[B] cached tokens each) on a
  * synthetic cache; part_tokens > 0 splits every context into workgroups of that many tokens */
 int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int hd, const int32_t* ctx_lens, int part_tokens,

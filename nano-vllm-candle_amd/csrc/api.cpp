@@ -266,6 +266,7 @@ static int dmalloc(nvllm_ctx* c, T** p, size_t count) {
 // ---------------------------------------------------------------------------------------------------
 // model
 // ---------------------------------------------------------------------------------------------------
+constexpr int kFusedMaxRows = 128;  // the fused decode path (deferred norms, row-parallel epilogues) handles up to this many rows
 constexpr int kAttnMaxParts = 64;  // split-KV partitions per sequence (partition grows with context beyond 8K)
 
 struct LayerW {
@@ -305,7 +306,9 @@ struct nvllm_model {
     int *d_pos = nullptr, *d_slot = nullptr, *d_tile_row0 = nullptr, *d_tile_nrows = nullptr, *d_tile_slot = nullptr,
         *d_last_rows = nullptr;
     float *resid = nullptr, *slabs = nullptr, *qbuf = nullptr, *logits = nullptr, *d_maxval = nullptr, *red = nullptr;
-    bf16_bits *xh = nullptr, *xl = nullptr, *xh2 = nullptr, *xl2 = nullptr;
+    bf16_bits *xh = nullptr, *xl = nullptr, *xh2 = nullptr, *xl2 = nullptr, *ctxh = nullptr, *ctxl = nullptr;
+    float *ssqA = nullptr, *ssqB = nullptr;  // deferred-norm partial sums of squares [groups][kFusedMaxRows]
+    bool fused_ok = false;                   // row-parallel fused decode path available for this model's shapes
     uint32_t* d_next = nullptr;
     float *attn_po = nullptr, *attn_pml = nullptr;  // split-KV partials [max_seqs][nh_l][kAttnMaxParts][hd] / [..][2]
     int attn_part_tiles = 4, attn_parts_max = 1;   // this step's split geometry (decode only)
@@ -425,11 +428,11 @@ static void free_kv(nvllm_model* m) {
     for (auto p : m->vcache) (void)hipFree(p);
     m->kcache.clear(); m->vcache.clear();
     void* ptrs[] = {m->d_block_tables, m->d_ids, m->d_pos, m->d_slot, m->d_tile_row0, m->d_tile_nrows, m->d_tile_slot,
-                    m->d_last_rows, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->xh2, m->xl2, m->d_next,
+                    m->d_last_rows, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->xh2, m->xl2, m->ctxh, m->ctxl, m->ssqA, m->ssqB, m->d_next,
                     m->part_val, m->part_idx, m->argmax_scratch, m->attn_po, m->attn_pml, m->tap_h, m->tap_res, m->cosv, m->sinv};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     m->d_block_tables = nullptr; m->d_ids = nullptr; m->d_pos = m->d_slot = m->d_tile_row0 = m->d_tile_nrows = m->d_tile_slot = m->d_last_rows = nullptr;
-    m->resid = m->slabs = m->qbuf = m->logits = m->d_maxval = m->red = nullptr; m->xh = m->xl = m->xh2 = m->xl2 = nullptr; m->d_next = nullptr; m->part_val = nullptr; m->part_idx = nullptr; m->argmax_scratch = nullptr; m->attn_po = m->attn_pml = nullptr;
+    m->resid = m->slabs = m->qbuf = m->logits = m->d_maxval = m->red = nullptr; m->xh = m->xl = m->xh2 = m->xl2 = m->ctxh = m->ctxl = nullptr; m->ssqA = m->ssqB = nullptr; m->d_next = nullptr; m->part_val = nullptr; m->part_idx = nullptr; m->argmax_scratch = nullptr; m->attn_po = m->attn_pml = nullptr;
     m->tap_h = m->tap_res = nullptr; m->cosv = m->sinv = nullptr;
     if (m->h_stage) (void)hipHostFree(m->h_stage);
     m->h_stage = nullptr;
@@ -691,6 +694,14 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->d_maxval, (size_t)max_seqs * std::max(1, ctx->tp_size) * 2);
     if (!rc) rc = dmalloc(ctx, &m->xh, R * wide);
     if (!rc) rc = dmalloc(ctx, &m->xl, R * wide);
+    m->fused_ok = ctx->tp_size == 1 && gemm_rowpar_supported(m->H, m->nh_l * m->hd) && gemm_rowpar_supported(m->H, m->I_l);
+    {
+        const size_t g = std::max<size_t>({(size_t)1, (size_t)gemm_rowpar_groups(m->H, m->nh_l * m->hd), (size_t)gemm_rowpar_groups(m->H, m->I_l)});
+        if (!rc) rc = dmalloc(ctx, &m->ssqA, g * kFusedMaxRows);
+        if (!rc) rc = dmalloc(ctx, &m->ssqB, g * kFusedMaxRows);
+    }
+    if (!rc) rc = dmalloc(ctx, &m->ctxh, R * (size_t)m->nh_l * m->hd);
+    if (!rc) rc = dmalloc(ctx, &m->ctxl, R * (size_t)m->nh_l * m->hd);
     if (!rc) rc = dmalloc(ctx, &m->xh2, R * (size_t)m->I_l);
     if (!rc) rc = dmalloc(ctx, &m->xl2, R * (size_t)m->I_l);
     if (!rc) rc = dmalloc(ctx, &m->d_next, (size_t)max_seqs * (ctx->tp_size + 1));
@@ -788,8 +799,113 @@ static int tp_reduce(nvllm_model* m, int rows, int ns, const float** in, int* n_
     return NVLLM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused decode forward (tp == 1, R <= kFusedMaxRows): 5 launches per layer instead of 9.
+//   QKV GEMM (slabs) -> attention (q/k-norm + RoPE + KV write in the prologue for single-row tiles)
+//   -> o_proj row-parallel GEMM (+ residual, next-norm prep) -> gate/up GEMM (+ SiLU*mul)
+//   -> down_proj row-parallel GEMM (+ residual, next-norm prep).
+// The two RMSNorm launches per layer disappear: the row-parallel epilogue writes x' = w_next (.) resid and
+// the row's partial sums of squares; every consumer multiplies its (linear) result by rinv[row] (RowNorm).
+// ---------------------------------------------------------------------------------------------------
+static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n_last, int logits_row0) {
+    nvllm_ctx* ctx = m->ctx;
+    hipStream_t s = ctx->stream;
+    const int H = m->H, hd = m->hd;
+    const float eps = (float)m->cfg.rms_norm_eps;
+    const int NQ = (m->nh_l + 2 * m->kv_l) * hd;
+    const int KO = m->nh_l * hd;
+    m->tap_rows = R;
+    RowNorm rn;  // the norm pending on xh/xl
+    rn.stride = kFusedMaxRows; rn.inv_h = 1.0f / (float)H; rn.eps = eps;
+    {   // layer 0 input: residual = embedding row, x' = ln1 (.) row, ssq (qwen3.rs:382-386, 465-468)
+        NormArgs na;
+        na.ids = m->d_ids; na.embed = m->embed; na.weight = m->layers[0].ln1; na.eps = eps; na.H = H;
+        na.xh = m->xh; na.xl = m->xl; na.residual_out = m->resid; na.ssq_out = m->ssqB;
+        PROF(m, PROF_NORM, launch_add_rmsnorm(na, R, s));
+        rn.ssq = m->ssqB; rn.groups = 1;
+    }
+    for (int l = 0; l < m->L; ++l) {
+        const LayerW& w = m->layers[l];
+        QkvArgs qa;
+        {   // QKV projection: whole-K row-parallel kernel (one f32 result, no slabs) when the shape allows
+            RowParArgs rq;
+            rq.xh = m->xh; rq.xl = m->xl; rq.ldx = H; rq.out = m->slabs; rq.M = R;
+            hipError_t e = launch_gemm_rowpar(rq, w.qkv, 2, s);
+            if (e == hipErrorNotSupported) {
+                GemmPlan pq = plan_gemm(R, NQ, H, 8);
+                PROF(m, PROF_GEMM, launch_gemm(pq, m->xh, m->xl, H, w.qkv, m->slabs, R, s));
+                qa.n_slabs = pq.n_split;
+            } else {
+                HIPCHK(ctx, e);
+                qa.n_slabs = 1;
+            }
+        }
+        qa.qkv = m->slabs; qa.slab_stride = (int64_t)R * NQ; qa.qn = w.qn; qa.kn = w.kn; qa.eps = eps;
+        qa.cos = m->cosv; qa.sin = m->sinv; qa.pos = m->d_pos; qa.slot = m->d_slot; qa.block_tables = m->d_block_tables;
+        qa.max_blocks = m->max_blocks; qa.nh_l = m->nh_l;
+        qa.q_scale = powf((float)hd, -0.5f) * 1.4426950408889634f;
+        qa.q_out = m->qbuf; qa.rn = rn;
+        qa.kv.k = m->kcache[l]; qa.kv.v = m->vcache[l]; qa.kv.kv_l = m->kv_l; qa.kv.hd = hd;
+        const bool fuse_qk = qt == 1 && n_tiles == R;
+        if (!fuse_qk) PROF(m, PROF_QK, launch_qk_norm_rope_kvwrite(qa, R, s));
+        AttnArgs aa;
+        aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
+        aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
+        aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->ctxh; aa.out_lo = m->ctxl;
+        if (fuse_qk) {
+            aa.qkv = qa.qkv; aa.n_slabs = qa.n_slabs; aa.slab_stride = qa.slab_stride; aa.ldqkv = NQ; aa.qn = w.qn; aa.kn = w.kn;
+            aa.cos = m->cosv; aa.sin = m->sinv; aa.eps = eps; aa.q_scale = qa.q_scale; aa.rn = rn;
+        }
+        int parts_max = 1;
+        if (qt == 1 && R <= m->max_seqs) {
+            aa.part_tiles = m->attn_part_tiles; aa.max_parts = kAttnMaxParts; aa.part_o = m->attn_po; aa.part_ml = m->attn_pml;
+            parts_max = m->attn_parts_max;
+        }
+        PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
+        // o_proj + residual + post-attention norm prep (qwen3.rs:278, :393)
+        RowParArgs ra;
+        ra.xh = m->ctxh; ra.xl = m->ctxl; ra.ldx = KO; ra.resid_in = m->resid; ra.resid_out = m->resid; ra.next_w = w.ln2;
+        ra.oh = m->xh; ra.ol = m->xl; ra.ssq = m->ssqA; ra.ssq_stride = kFusedMaxRows; ra.M = R;
+        PROF(m, PROF_GEMM, launch_gemm_rowpar(ra, w.o, 0, s));
+        rn.ssq = m->ssqA; rn.groups = gemm_rowpar_groups(H, KO);
+        // gate/up + SiLU*mul (qwen3.rs:324-325), scaled by the pending norm's rinv
+        {
+            RowParArgs rg;
+            rg.xh = m->xh; rg.xl = m->xl; rg.ldx = H; rg.oh = m->xh2; rg.ol = m->xl2; rg.M = R; rg.rn = rn;
+            hipError_t e = launch_gemm_rowpar(rg, w.gu, 1, s);
+            if (e == hipErrorNotSupported) {
+                GemmPlan pg = plan_gemm_swiglu(R, 2 * m->I_l, H);
+                gemm_set_rownorm(&rn);
+                PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, s));
+            } else {
+                HIPCHK(ctx, e);
+            }
+        }
+        // down_proj + residual + next layer's input norm prep (qwen3.rs:326, next layer :378; last layer: final norm :497)
+        RowParArgs rd;
+        rd.xh = m->xh2; rd.xl = m->xl2; rd.ldx = m->I_l; rd.resid_in = m->resid; rd.resid_out = m->resid;
+        rd.next_w = l + 1 < m->L ? m->layers[l + 1].ln1 : m->norm;
+        rd.oh = m->xh; rd.ol = m->xl; rd.ssq = m->ssqB; rd.ssq_stride = kFusedMaxRows; rd.M = R;
+        PROF(m, PROF_GEMM, launch_gemm_rowpar(rd, w.down, 0, s));
+        rn.ssq = m->ssqB; rn.groups = gemm_rowpar_groups(H, m->I_l);
+    }
+    if (n_last > 0) {
+        // LM head on the last-token rows only (gathered by row_idx), logits scaled by the final norm's rinv
+        GemmPlan pl = plan_gemm(n_last, m->V_l, H, 1);
+        float* lg = m->want_logits ? m->logits + (size_t)logits_row0 * m->V_l : nullptr;
+        rn.row_idx = m->d_last_rows;
+        gemm_set_rownorm(&rn);
+        PROF(m, PROF_LMHEAD, launch_gemm_argmax(pl, m->xh, m->xl, H, m->lm_head, lg, n_last, m->part_val, m->part_idx, s));
+        HIPCHK(ctx, launch_argmax_parts(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, m->argmax_scratch,
+                                        m->d_next + logits_row0, nullptr, s));
+    }
+    return NVLLM_OK;
+}
+
 // rows R (ids/pos/slot/tiles already on the device), n_last rows listed in d_last_rows -> logits rows
 static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last, int logits_row0) {
+    if (m->fused_ok && R <= kFusedMaxRows && !m->taps && !getenv("NVLLM_NO_FUSED"))
+        return forward_chunk_fused(m, R, n_tiles, qt, n_last, logits_row0);
     nvllm_ctx* ctx = m->ctx;
     hipStream_t s = ctx->stream;
     const int H = m->H, hd = m->hd;
@@ -1465,6 +1581,46 @@ extern "C" int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int
         a.kv.k = rk[i % nrot]; a.kv.v = rv[i % nrot];
         HIPCHK(ctx, launch_attn_paged(a, B, 1, B, parts_max, s));
     }
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *us_per_call = ms * 1e3f / iters;
+    return NVLLM_OK;
+}
+
+// tuning aid, v2: mode 0 = slabs, 2 = SwiGLU epilogue (N = 2I); mt = m-tiles per workgroup (0 = planner);
+// `rot` weight copies are cycled so every launch streams cold HBM like the model does (1 = cache-warm).
+extern "C" int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int mt, int nt, int nw, int n_split, int mode,
+                                       int rot, int iters, float* us_per_call) {
+    if (!ctx || !us_per_call || M < 1 || N % 32 || K % 128 || iters < 1 || rot < 1) return fail(ctx, NVLLM_EINVAL, "bad gemm_bench2 arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    GemmPlan p = mode == 2 ? plan_gemm_swiglu(M, N, K) : plan_gemm(M, N, K, 64);
+    if (mt > 0) { p.mt = mt; p.kc = mt == 8 ? 2 : 4; }
+    if (nt > 0) p.nt = nt;
+    if (nw > 0) p.nw = nw;
+    set_split(p, K / 32, n_split > 0 ? n_split : p.n_split);
+    TmpBufs t;
+    std::vector<PackedW> ws(rot);
+    for (int r = 0; r < rot; ++r) {
+        ws[r].N = N; ws[r].K = K;
+        HIPCHK(ctx, t.get(&ws[r].data, (size_t)N * K / 8));
+        HIPCHK(ctx, launch_synth_packed(ws[r], 0, N, 12345 + r, 0, 0, K, -1, s));
+    }
+    bf16_bits *xh, *xl, *ah, *al; float* out;
+    HIPCHK(ctx, t.get(&xh, (size_t)M * K)); HIPCHK(ctx, t.get(&xl, (size_t)M * K));
+    HIPCHK(ctx, t.get(&ah, (size_t)M * N)); HIPCHK(ctx, t.get(&al, (size_t)M * N));
+    HIPCHK(ctx, t.get(&out, (size_t)p.n_split * M * N));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(xh, 777, kSynthMatrix, 0, (int64_t)M * K, s));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(xl, 778, kSynthMatrix, 0, (int64_t)M * K, s));
+    auto go = [&](int i) -> hipError_t {
+        const PackedW& w = ws[i % rot];
+        return mode == 2 ? launch_gemm_swiglu(p, xh, xl, K, w, M, ah, al, s) : launch_gemm(p, xh, xl, K, w, out, M, s);
+    };
+    for (int i = 0; i < 3; ++i) HIPCHK(ctx, go(i));
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(ctx, go(i));
     HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
     HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0;

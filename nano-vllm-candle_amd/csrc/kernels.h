@@ -40,6 +40,21 @@ hipError_t launch_bf16_to_f32(const bf16_bits* src, float* dst, int64_t n, hipSt
 // x f32 [rows][n] -> hi/lo bf16 planes (hi = bf16(x), lo = bf16(x - hi))
 hipError_t launch_split_hilo(const float* x, bf16_bits* hi, bf16_bits* lo, int64_t n, hipStream_t s);
 
+// ---- deferred RMSNorm (fused decode path) -------------------------------------------------------------
+// A row-parallel GEMM epilogue (gemm_rowpar) writes the new residual s, x' = w_next (.) s (the NEXT norm's weight
+// folded in, but NOT the 1/rms factor) and per-row partial sums of squares ssq[group][row].  Because the
+// consumer is linear in x, it applies rinv[row] = 1/sqrt(sum_g ssq[g][row]/H + eps) to its OUTPUT instead:
+//   norm(s).W^T = rinv * ((w (.) s).W^T)          (layernorm.rs:55-57 semantics, f32)
+// ssq == nullptr means the activations are already normalised (rinv = 1).
+struct RowNorm {
+    const float* ssq = nullptr;  // [groups][stride]
+    int groups = 0;
+    int stride = 0;              // rows allocated per group
+    float inv_h = 0.f;           // 1 / hidden_size
+    float eps = 0.f;
+    const int* row_idx = nullptr;  // GEMM only: x row (and ssq row) of output row r
+};
+
 // ---- GEMM: out[ks][M][N] = x[M][K-slice ks] . W[N][K-slice ks]^T  (f32 slabs, ks < n_split) ------
 struct GemmPlan {
     int mt, nt, nw, kc;  // m-tiles per WG, n-tiles per wave, waves per WG, k-tiles per LDS chunk
@@ -50,6 +65,7 @@ GemmPlan plan_gemm(int M, int N, int K, int max_split);  // K % 128 == 0 require
 void set_split(GemmPlan& p, int KT, int want);
 hipError_t launch_gemm(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
                        float* out, int M, hipStream_t s);
+void gemm_set_rownorm(const RowNorm* rn);  // applies to the NEXT launch_gemm_argmax / launch_gemm_swiglu only
 // same GEMM (n_split must be 1) whose epilogue also emits per-wave partial arg-max (LAST max wins):
 // part_val/part_idx [gemm_argmax_parts(p, N)][M]; `out` may be nullptr (ids only, logits never stored)
 hipError_t launch_gemm_argmax(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
@@ -79,6 +95,7 @@ struct NormArgs {
     bf16_bits* xh = nullptr;          // outputs (nullable individually)
     bf16_bits* xl = nullptr;
     float* y = nullptr;
+    float* ssq_out = nullptr;         // prep mode (fused decode path): outputs are w (.) s (no 1/rms) and ssq_out[r] = sum s^2
 };
 hipError_t launch_add_rmsnorm(const NormArgs& a, int rows, hipStream_t s);
 
@@ -105,6 +122,7 @@ struct QkvArgs {
     float q_scale = 1.f;         // folded into q: head_dim^-0.5 * log2(e)
     float* q_out = nullptr;      // [rows][nh_l*hd] f32
     KvLayout kv;
+    RowNorm rn;                  // deferred input norm (qkv sums are multiplied by rinv[row] first)
 };
 hipError_t launch_qk_norm_rope_kvwrite(const QkvArgs& a, int rows, hipStream_t s);
 
@@ -132,6 +150,7 @@ struct AttnArgs {
     const float* cos = nullptr;
     const float* sin = nullptr;
     float eps = 1e-6f, q_scale = 1.f;
+    RowNorm rn;                        // deferred input norm for the fused prologue
     // split-KV (decode): each workgroup covers part_tiles 32-token tiles; partials merged by a combine pass
     int part_tiles = 0, max_parts = 0;
     float* part_o = nullptr;           // [rows][nh_l][max_parts][hd]
@@ -140,6 +159,32 @@ struct AttnArgs {
 // qt = q sub-tiles (of 16 MFMA rows) per workgroup: 1 (decode) or 2 (prefill)
 hipError_t launch_attn_paged(const AttnArgs& a, int n_tiles, int qt, int rows, int n_parts_max, hipStream_t s);
 inline int attn_tokens_per_tile(int gqa, int qt) { return (16 / gqa) * qt; }
+
+// ---- row-parallel projection with residual + next-norm epilogue (decode, tp == 1) ---------------------
+// resid_out = resid_in + x.W^T ; x' = next_w (.) resid_out as bf16 hi/lo ; ssq[group][row] partial sums of squares.
+// One workgroup owns 16 rows x (NWN*16) features for the WHOLE K (waves split K, reduced through LDS), all loads
+// issued up front.  Returns hipErrorNotSupported when (K, N) has no supported decomposition.
+struct RowParArgs {
+    const bf16_bits* xh = nullptr;
+    const bf16_bits* xl = nullptr;
+    int ldx = 0;
+    const float* resid_in = nullptr;
+    float* resid_out = nullptr;
+    const float* next_w = nullptr;
+    bf16_bits* oh = nullptr;
+    bf16_bits* ol = nullptr;
+    float* ssq = nullptr;  // [groups][ssq_stride]
+    int ssq_stride = 0;
+    int M = 0;
+    // epilogue 1 (SwiGLU): w = interleaved gate/up, writes act hi/lo [M][N/2] (oh/ol), input norm rn deferred
+    // epilogue 2 (plain): out f32 [M][N]
+    float* out = nullptr;
+    RowNorm rn;
+};
+bool gemm_rowpar_supported(int N, int K);
+int gemm_rowpar_groups(int N, int K);
+// epi: 0 residual + next-norm prep, 1 SwiGLU, 2 plain f32 output
+hipError_t launch_gemm_rowpar(const RowParArgs& a, const PackedW& w, int epi, hipStream_t s);
 
 // ---- SwiGLU -----------------------------------------------------------------------------------------
 // gu [n_slabs][rows][2*I] -> act hi/lo [rows][I] (and/or f32 y)

@@ -35,6 +35,48 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// rinv[row] of a deferred RMSNorm (see RowNorm); 1 when the activations were normalised by the producer
+__device__ __forceinline__ float rownorm_rinv(const RowNorm& rn, int row) {
+    if (!rn.ssq) return 1.0f;
+    float t = 0.f;
+    for (int g = 0; g < rn.groups; ++g) t += rn.ssq[(size_t)g * rn.stride + row];
+    return 1.0f / sqrtf(t * rn.inv_h + rn.eps);
+}
+
+// Workgroup-cooperative form for kernels whose epilogue needs rinv of up to NR rows: every thread sums a
+// strided quarter of the groups of one row with independent (unrollable) loads and parks it in LDS;
+// after any later barrier rownorm_rinv_lds() finishes the sum.  groups <= 64.
+template <int NR>
+__device__ __forceinline__ void rownorm_partials(const RowNorm& rn, int m0, int M, float* lds_part) {
+    if (!rn.ssq) return;
+    for (int idx = threadIdx.x; idx < 4 * NR; idx += blockDim.x) {
+        const int r = idx % NR, part = idx / NR;
+        int row = min(m0 + r, M - 1);
+        if (rn.row_idx) row = rn.row_idx[row];
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int g = part + 4 * i;
+            const float v = rn.ssq[(size_t)min(g, rn.groups - 1) * rn.stride + row];
+            t += g < rn.groups ? v : 0.f;
+        }
+        lds_part[part * NR + r] = t;
+    }
+}
+template <int NR>
+__device__ __forceinline__ float rownorm_rinv_lds(const RowNorm& rn, const float* lds_part, int r) {
+    if (!rn.ssq) return 1.0f;
+    const float t = lds_part[r] + lds_part[NR + r] + lds_part[2 * NR + r] + lds_part[3 * NR + r];
+    return 1.0f / sqrtf(t * rn.inv_h + rn.eps);
+}
+// one row, one wave: lane g loads group g (groups <= 64)
+__device__ __forceinline__ float rownorm_rinv_wave(const RowNorm& rn, int row, int lane) {
+    if (!rn.ssq) return 1.0f;
+    float t = lane < rn.groups ? rn.ssq[(size_t)lane * rn.stride + row] : 0.f;
+    t = wave_sum(t);
+    return 1.0f / sqrtf(t * rn.inv_h + rn.eps);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // weight packing / synthetic fill
 // ---------------------------------------------------------------------------------------------------
@@ -179,13 +221,14 @@ template <int MT, int NT, int NW, int KC, int MODE>
 __global__ void __launch_bounds__(NW * 64)
 gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, int ldx, const uint4* __restrict__ wp,
             float* __restrict__ out, int M, int N, int KT, int kt_per_split, float* __restrict__ part_val,
-            int* __restrict__ part_idx, uint16_t* __restrict__ act_hi, uint16_t* __restrict__ act_lo) {
+            int* __restrict__ part_idx, uint16_t* __restrict__ act_hi, uint16_t* __restrict__ act_lo, RowNorm rn) {
     // LDS: two buffers of [2 planes][MT][KC][64 lanes] 16-byte slots, filled by LDS-DMA (global_load_lds):
     // the image is lane-linear per fragment, so every wave-DMA writes one contiguous 1 KiB and every
     // ds_read_b128 of a fragment is conflict-free.
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     uint4* lds = reinterpret_cast<uint4*>(smem_raw);
     constexpr int FRAGS = 2 * MT * KC;  // per buffer
+    float* lds_rn = reinterpret_cast<float*>(smem_raw + (size_t)2 * FRAGS * 1024);  // [4][MT*16] deferred-norm partials
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, grp = lane >> 4;
     const int ntiles = N >> 4;
@@ -204,6 +247,12 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
     // Two named register sets / LDS buffers (static indices only: a runtime-selected set would make
     // every MFMA depend on the loads still in flight for the other one).
     uint4 wf0[NT][KC], wf1[NT][KC];
+    int xrows[MT];  // staged row of each m-tile for this lane (gathered once: LM head on last tokens only)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+        xrows[b] = min(m0 + b * 16 + l15, M - 1);
+        if (rn.row_idx) xrows[b] = rn.row_idx[xrows[b]];
+    }
     // issue the loads of one chunk: weight fragments -> VGPRs, activation fragments -> LDS by DMA.
     // Rows >= M and k-tiles past the split are clamped to valid addresses: their products are never
     // stored (rows) or meet zeroed weight fragments (k), so only finiteness matters.
@@ -225,7 +274,7 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
                 const int plane = f / (MT * KC);
                 const int rem = f - plane * (MT * KC);
                 const int mt = rem / KC, k = rem - mt * KC;
-                const int row = min(m0 + mt * 16 + l15, M - 1);
+                const int row = xrows[mt];
                 const uint16_t* src = (plane ? xl : xh) + (size_t)row * ldx + (size_t)(kc + k) * 32 + grp * 8;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (size_t)(buf * FRAGS + f) * 64), 16, 0, 0);
             }
@@ -257,12 +306,15 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
         // every decode-shape split -- costs ONE memory round trip instead of two dependent ones.
         if (nchunks > 0) issue(0, 0, wf0);
         if (nchunks > 1) issue(1, 1, wf1);
+        // deferred-norm partials: loaded AFTER the main loads were issued (vmcnt is in order), parked in LDS
+        if constexpr (MODE != 0) rownorm_partials<MT * 16>(rn, m0, M, lds_rn);
         __syncthreads();  // vmcnt(0) + barrier: everything has landed
         if (nchunks > 0) compute(0, wf0);
         if (nchunks > 1) compute(1, wf1);
     } else {
         // long K (LM head, prefill): one chunk ahead, one barrier per chunk
         issue(0, 0, wf0);
+        if constexpr (MODE != 0) rownorm_partials<MT * 16>(rn, m0, M, lds_rn);
         for (int c = 0; c < nchunks; c += 2) {
             __syncthreads();  // chunk c has landed; buffer 1 is free again
             if (c + 1 < nchunks) issue(c + 1, 1, wf1);
@@ -271,6 +323,18 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
             __syncthreads();
             if (c + 2 < nchunks) issue(c + 2, 0, wf0);
             compute(1, wf1);
+        }
+    }
+    if constexpr (MODE == 1) {  // LM head on a deferred final norm: logits = rinv[row] * acc
+        if (rn.ssq) {
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const float ri = rownorm_rinv_lds<MT * 16>(rn, lds_rn, b * 16 + l15);
+#pragma unroll
+                for (int a = 0; a < NT; ++a) {
+                    acc[a][b][0] *= ri; acc[a][b][1] *= ri; acc[a][b][2] *= ri; acc[a][b][3] *= ri;
+                }
+            }
         }
     }
     // D[feature 4*grp+reg][token l15] -> out[token][feature..feature+3]
@@ -299,10 +363,11 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
             for (int b = 0; b < MT; ++b) {
                 const int row = m0 + b * 16 + l15;
                 if (row < M) {
+                    const float ri = rownorm_rinv_lds<MT * 16>(rn, lds_rn, b * 16 + l15);
                     uint16_t h[4], l[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float g = acc[0][b][r], u = acc[NT - 1][b][r];
+                        const float g = acc[0][b][r] * ri, u = acc[NT - 1][b][r] * ri;
                         split_bf16((g / (1.0f + __expf(-g))) * u, h[r], l[r]);
                     }
                     *reinterpret_cast<uint2*>(act_hi + (size_t)row * I + f0) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
@@ -428,6 +493,7 @@ struct GemmExtra {
     int* part_idx = nullptr;
     bf16_bits* act_hi = nullptr; // MODE 2
     bf16_bits* act_lo = nullptr;
+    RowNorm rn;
 };
 
 template <int MT, int NT, int NW, int KC, int MODE>
@@ -435,7 +501,7 @@ static hipError_t gemm_launch_t(const GemmPlan& p, const bf16_bits* xh, const bf
                                 float* out, int M, const GemmExtra& x, hipStream_t s) {
     const int ntiles = w.N / 16;
     dim3 grid((ntiles + NT * NW - 1) / (NT * NW), p.n_split, (M + MT * 16 - 1) / (MT * 16));
-    const size_t lds = (size_t)2 * 2 * MT * KC * 1024;
+    const size_t lds = (size_t)2 * 2 * MT * KC * 1024 + (size_t)4 * MT * 16 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<MT, NT, NW, KC, MODE>),
@@ -443,7 +509,7 @@ static hipError_t gemm_launch_t(const GemmPlan& p, const bf16_bits* xh, const bf
         attr_set = true;
     }
     gemm_kernel<MT, NT, NW, KC, MODE><<<grid, NW * 64, lds, s>>>(xh, xl, ldx, w.data, out, M, w.N, w.K / 32, p.kt_per_split,
-                                                                x.part_val, x.part_idx, x.act_hi, x.act_lo);
+                                                                x.part_val, x.part_idx, x.act_hi, x.act_lo, x.rn);
     return hipGetLastError();
 }
 
@@ -476,6 +542,9 @@ static hipError_t gemm_dispatch(const GemmPlan& p, const bf16_bits* xh, const bf
     return hipErrorInvalidValue;
 }
 
+static RowNorm g_next_rownorm;  // consumed (and cleared) by the next argmax / swiglu launch
+void gemm_set_rownorm(const RowNorm* rn) { g_next_rownorm = rn ? *rn : RowNorm{}; }
+
 hipError_t launch_gemm(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
                        float* out, int M, hipStream_t s) {
     return gemm_dispatch<0>(p, xh, xl, ldx, w, out, M, GemmExtra{}, s);
@@ -486,6 +555,7 @@ hipError_t launch_gemm_argmax(const GemmPlan& p, const bf16_bits* xh, const bf16
     if (!part_val || !part_idx || p.n_split != 1) return hipErrorInvalidValue;
     GemmExtra x;
     x.part_val = part_val; x.part_idx = part_idx;
+    x.rn = g_next_rownorm; g_next_rownorm = RowNorm{};
     return gemm_dispatch<1>(p, xh, xl, ldx, w, out, M, x, s);
 }
 
@@ -495,13 +565,20 @@ hipError_t launch_gemm_swiglu(const GemmPlan& p, const bf16_bits* xh, const bf16
     if (p.nt != 2 || p.n_split != 1 || !act_hi || !act_lo) return hipErrorInvalidValue;
     GemmExtra x;
     x.act_hi = act_hi; x.act_lo = act_lo;
+    x.rn = g_next_rownorm; g_next_rownorm = RowNorm{};
     return gemm_dispatch<2>(p, xh, xl, ldx, w, nullptr, M, x, s);
 }
 GemmPlan plan_gemm_swiglu(int M, int N2, int K) {
     GemmPlan p = plan_gemm(M, N2, K, 1);
     p.nt = 2;
-    // few rows: many small workgroups (each wave streams its own two tiles); many rows: share x across 4 waves
-    p.nw = M <= 128 ? 2 : 4;
+    if (M <= 128) {
+        // decode: no K-split is possible (the epilogue needs whole sums), so parallelism comes from splitting
+        // the ROWS over workgroups (16 rows each); the weight tiles are re-read through L2 by the row blocks.
+        // Measured cold, M=64 0.6B gate_up: mt=1/nw=2 9.8 us vs mt=4/nw=2 15.8 us (tools/tune_gemm2.py)
+        p.mt = 1; p.kc = 4; p.nw = 2;
+    } else {
+        p.nw = 4;
+    }
     set_split(p, K / 32, 1);
     return p;
 }
@@ -517,6 +594,208 @@ hipError_t launch_argmax_parts(const float* part_val, const int* part_idx, int n
     dim3 grid(std::max(1, std::min(64, n_parts / 64)), (M + 63) / 64);
     argmax_parts_kernel<<<grid, 256, 0, s>>>(part_val, part_idx, n_parts, M, keys, ticket, ids, maxval);
     return hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Row-parallel projection (o_proj, down_proj) for decode with a residual + next-norm epilogue.
+// Replaces: RowParallelLinear::forward (linear.rs:184-198) + the following RMSNorm::forward(x, residual)
+// (layernorm.rs:44-60; qwen3.rs:393 / :378 of the next layer): resid += x.W^T ; x' = w_next (.) resid ;
+// ssq[group][row] = partial sum of squares (the consumer applies 1/rms, see RowNorm).
+//
+// One workgroup = 16 rows x NWN n-tiles; its NWN*NWK waves split K NWK ways.  EVERY load of the workgroup
+// is issued before the first wait: each wave's PH*TPW weight fragments (HBM -> VGPR) and the x fragments of
+// phase 0 (LDS-DMA, shared by all waves).  K ranges too large for LDS run in PH = 2 phases (the second x
+// image comes from L2 while the weights are already in registers).  Partial sums meet in LDS, the k-slice-0
+// waves run the epilogue.  Rows are split over blockIdx.z (weights re-read through L2 by the row blocks).
+// ---------------------------------------------------------------------------------------------------
+template <int NWN, int NWK, int TPW, int PH, int EPI>
+__global__ void __launch_bounds__(NWN * NWK * 64) gemm_rowpar_kernel(RowParArgs a, const uint4* __restrict__ wp, int N, int KT) {
+    constexpr int NW = NWN * NWK;
+    constexpr int KTP = NWK * TPW;            // k-tiles per phase (<= 32: one x image <= 64 KiB)
+    constexpr int NBUF = PH > 1 ? 2 : 1;      // x images resident at once
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint4* lds_x = reinterpret_cast<uint4*>(smem_raw);                                  // [NBUF][2 planes][KTP][64]
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw + (size_t)NBUF * 2 * KTP * 1024);    // [NW][64]
+    float* sred = reinterpret_cast<float*>(smem_raw + (size_t)NBUF * 2 * KTP * 1024 + (size_t)NW * 1024);  // [NWN][16] / rinv partials [4][16]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int wn = wave / NWK, wk = wave % NWK;
+    const int ntiles = N >> 4;
+    const int ntile = min((int)blockIdx.x * NWN + wn, ntiles - 1);
+    const int m0 = blockIdx.z * 16;
+    const int M = a.M;
+
+    // every weight fragment of this wave, all phases, issued before anything else (HBM -> VGPR)
+    uint4 w[PH][TPW];
+#pragma unroll
+    for (int p = 0; p < PH; ++p)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) w[p][t] = wp[((size_t)ntile * KT + p * KTP + wk * TPW + t) * 64 + lane];
+
+    const int xrow = min(m0 + l15, M - 1);
+    auto stage = [&](int p, int buf) {
+#pragma unroll
+        for (int i = 0; i < (2 * KTP) / NW; ++i) {
+            const int f = wave + i * NW;
+            const int plane = f / KTP, k = f - plane * KTP;
+            const uint16_t* src = (plane ? a.xl : a.xh) + (size_t)xrow * a.ldx + (size_t)(p * KTP + k) * 32 + grp * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_x + (size_t)(buf * 2 * KTP + f) * 64), 16, 0, 0);
+        }
+    };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const uint4 (&wf)[TPW], int buf) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int kl = wk * TPW + t;
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, lds_x[(size_t)(buf * 2 * KTP + kl) * 64 + lane]);
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, lds_x[(size_t)(buf * 2 * KTP + KTP + kl) * 64 + lane]);
+            const bf16x8 wv = __builtin_bit_cast(bf16x8, wf[t]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, bl, acc, 0, 0, 0);
+        }
+    };
+    // x images: the first two phases are in flight together with the weights (one memory round trip for
+    // K <= 2048); later phases are staged into the buffer that was just consumed
+    stage(0, 0);
+    if constexpr (PH > 1) stage(1, 1);
+    // epilogue operands are independent of the product: fetch them now, behind the streaming loads
+    const int row = m0 + l15;
+    const bool valid = (wk == 0) && row < M && ((int)blockIdx.x * NWN + wn) < ntiles;
+    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f), nw4 = r4;
+    if constexpr (EPI == 0) {
+        if (valid) {
+            r4 = *reinterpret_cast<const float4*>(a.resid_in + (size_t)row * N + (size_t)ntile * 16 + grp * 4);
+            nw4 = *reinterpret_cast<const float4*>(a.next_w + (size_t)ntile * 16 + grp * 4);
+        }
+    }
+    if constexpr (EPI == 1) rownorm_partials<16>(a.rn, m0, M, sred);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PH; ++p) {
+        compute(w[p], p & 1);
+        if (p + 2 < PH) {
+            __syncthreads();  // WAR: all waves are done with buffer p&1
+            stage(p + 2, p & 1);
+        }
+        if (p + 1 < PH && p + 2 < PH + 1 && p >= 1) __syncthreads();  // phase p+1 (staged after the first barrier) landed
+    }
+    red[(size_t)wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+        for (int k = 1; k < NWK; ++k) {
+            const f32x4 v = red[(size_t)(wn * NWK + k) * 64 + lane];
+            acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+        }
+    }
+    if constexpr (EPI == 0) {
+        float ssq_part = 0.f;
+        if (wk == 0) {
+            if (valid) {
+                const size_t o = (size_t)row * N + (size_t)ntile * 16 + grp * 4;
+                const float s0 = acc[0] + r4.x, s1 = acc[1] + r4.y, s2 = acc[2] + r4.z, s3 = acc[3] + r4.w;
+                *reinterpret_cast<float4*>(a.resid_out + o) = make_float4(s0, s1, s2, s3);
+                uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
+                split_bf16(s0 * nw4.x, h0, l0); split_bf16(s1 * nw4.y, h1, l1); split_bf16(s2 * nw4.z, h2, l2); split_bf16(s3 * nw4.w, h3, l3);
+                *reinterpret_cast<uint2*>(a.oh + o) = make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
+                *reinterpret_cast<uint2*>(a.ol + o) = make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
+                ssq_part = s0 * s0 + s1 * s1 + s2 * s2 + s3 * s3;
+            }
+            ssq_part += __shfl_xor(ssq_part, 16);
+            ssq_part += __shfl_xor(ssq_part, 32);
+            if (grp == 0) sred[wn * 16 + l15] = ssq_part;
+        }
+        __syncthreads();
+        if (wave == 0 && grp == 0 && row < M) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < NWN; ++k) t += sred[k * 16 + l15];
+            a.ssq[(size_t)blockIdx.x * a.ssq_stride + row] = t;
+        }
+    } else if constexpr (EPI == 1) {
+        // SwiGLU: n-tile 0 of the workgroup = gate, n-tile 1 = up of the same 16 features (interleaved weight)
+        static_assert(EPI != 1 || NWN == 2, "SwiGLU epilogue pairs two n-tiles");
+        if (wk == 0 && wn == 1) red[(size_t)(NWK) * 64 + lane] = acc;  // own slot: nobody else reads it before the barrier
+        __syncthreads();
+        if (wave == 0 && row < M && ((int)blockIdx.x * 2 + 1) < ntiles) {
+            const f32x4 up = red[(size_t)(NWK) * 64 + lane];
+            const float ri = rownorm_rinv_lds<16>(a.rn, sred, l15);
+            const int I = N >> 1;
+            uint16_t h[4], l[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float g = acc[r] * ri, u = up[r] * ri;
+                split_bf16((g / (1.0f + __expf(-g))) * u, h[r], l[r]);
+            }
+            const size_t o = (size_t)row * I + (size_t)blockIdx.x * 16 + grp * 4;
+            *reinterpret_cast<uint2*>(a.oh + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+            *reinterpret_cast<uint2*>(a.ol + o) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+        }
+    } else {
+        if (wk == 0 && row < M && ((int)blockIdx.x * NWN + wn) < ntiles)
+            *reinterpret_cast<float4*>(a.out + (size_t)row * N + (size_t)ntile * 16 + grp * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+struct RowParShape { int nwn, nwk, tpw, ph; };
+static bool rowpar_shape(int N, int K, RowParShape& sh) {
+    if (N % 16 || K % 32) return false;
+    const int KT = K / 32;
+    // fewest phases whose x image fits 64 KiB (KTP <= 32 k-tiles), most k-slices per workgroup first
+    static const int tpws[] = {8, 12, 16};
+    for (int ph = 1; ph <= 4; ++ph)
+        for (int nwk : {4, 2, 1})
+            for (int tpw : tpws) {
+                if (ph * nwk * tpw != KT || nwk * tpw > 32) continue;
+                const int nwn = (N / 16) % 2 == 0 ? 2 : 1;
+                if ((2 * tpw) % nwn) continue;
+                sh = {nwn, nwk, tpw, ph};
+                return true;
+            }
+    return false;
+}
+bool gemm_rowpar_supported(int N, int K) { RowParShape sh; return rowpar_shape(N, K, sh); }
+int gemm_rowpar_groups(int N, int K) { RowParShape sh; if (!rowpar_shape(N, K, sh)) return 0; return (N / 16 + sh.nwn - 1) / sh.nwn; }
+
+template <int NWN, int NWK, int TPW, int PH, int EPI>
+static hipError_t rowpar_launch_t(const RowParArgs& a, const PackedW& w, hipStream_t s) {
+    constexpr int NW = NWN * NWK, KTP = NWK * TPW, NBUF = PH > 1 ? 2 : 1;
+    const size_t lds = (size_t)NBUF * 2 * KTP * 1024 + (size_t)NW * 1024 + 4 * 16 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowpar_kernel<NWN, NWK, TPW, PH, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((w.N / 16 + NWN - 1) / NWN, 1, (a.M + 15) / 16);
+    gemm_rowpar_kernel<NWN, NWK, TPW, PH, EPI><<<grid, NW * 64, lds, s>>>(a, w.data, w.N, w.K / 32);
+    return hipGetLastError();
+}
+
+template <int EPI>
+static hipError_t rowpar_dispatch(const RowParShape& sh, const RowParArgs& a, const PackedW& w, hipStream_t s) {
+#define NVLLM_RP(NWN_, NWK_, TPW_, PH_) \
+    if (sh.nwn == NWN_ && sh.nwk == NWK_ && sh.tpw == TPW_ && sh.ph == PH_) return rowpar_launch_t<NWN_, NWK_, TPW_, PH_, EPI>(a, w, s);
+#define NVLLM_RP_PH(NWN_, PH_)                                                                        \
+    NVLLM_RP(NWN_, 4, 8, PH_) NVLLM_RP(NWN_, 2, 8, PH_) NVLLM_RP(NWN_, 2, 12, PH_) NVLLM_RP(NWN_, 2, 16, PH_) \
+    NVLLM_RP(NWN_, 1, 8, PH_) NVLLM_RP(NWN_, 1, 12, PH_) NVLLM_RP(NWN_, 1, 16, PH_)
+    NVLLM_RP_PH(2, 1) NVLLM_RP_PH(2, 2) NVLLM_RP_PH(2, 3) NVLLM_RP_PH(2, 4)
+    if constexpr (EPI != 1) { NVLLM_RP_PH(1, 1) NVLLM_RP_PH(1, 2) NVLLM_RP_PH(1, 3) NVLLM_RP_PH(1, 4) }
+#undef NVLLM_RP_PH
+#undef NVLLM_RP
+    return hipErrorNotSupported;
+}
+
+hipError_t launch_gemm_rowpar(const RowParArgs& a, const PackedW& w, int epi, hipStream_t s) {
+    RowParShape sh;
+    if (!rowpar_shape(w.N, w.K, sh)) return hipErrorNotSupported;
+    if (epi == 1 && sh.nwn != 2) return hipErrorNotSupported;
+    if (a.M <= 0) return hipSuccess;
+    if (epi == 0) return rowpar_dispatch<0>(sh, a, w, s);
+    if (epi == 1) return rowpar_dispatch<1>(sh, a, w, s);
+    if (epi == 2) return rowpar_dispatch<2>(sh, a, w, s);
+    return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -564,7 +843,9 @@ __global__ void __launch_bounds__(256) add_rmsnorm_kernel(NormArgs a) {
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
     ss = red[0] + red[1] + red[2] + red[3];
-    const float rinv = 1.0f / sqrtf(ss / (float)H + a.eps);
+    // prep mode: leave the 1/rms factor to the consumer (RowNorm) and publish the row's sum of squares
+    const float rinv = a.ssq_out ? 1.0f : 1.0f / sqrtf(ss / (float)H + a.eps);
+    if (a.ssq_out && threadIdx.x == 0) a.ssq_out[r] = ss;
 #pragma unroll
     for (int c = 0; c < kNormMaxV4; ++c) {
         const int i = threadIdx.x + c * 256;
@@ -632,6 +913,9 @@ __global__ void __launch_bounds__(256) qk_norm_rope_kvwrite_kernel(QkvArgs a) {
             x2 += p[(size_t)sl * a.slab_stride + lane + half];
         }
     }
+    const float ri = rownorm_rinv_wave(a.rn, row, lane);  // deferred input norm: the QKV sums are linear in x
+    x1 *= ri;
+    x2 *= ri;
     const int pos = a.pos[row];
     if (hh < a.nh_l + kv_l) {  // q or k head: norm + rope
         const float* w = hh < a.nh_l ? a.qn : a.kn;
@@ -786,6 +1070,7 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
         const int row = row0;
         const int pos = a.pos[row];
         const float* qkv_row = a.qkv + (size_t)row * a.ldqkv;
+        const float ri = rownorm_rinv_wave(a.rn, row, lane);  // deferred input norm of this row
         const bool owner = (pos >> 5) >= t_begin && (pos >> 5) < t_end;  // split-KV: one workgroup writes K/V
         if (wave == 0 && owner) {
             const bool act = lane < half;
@@ -802,6 +1087,8 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
                         x2 += p[(size_t)sl * a.slab_stride + lane + half];
                     }
                 }
+                x1 *= ri;
+                x2 *= ri;
                 if (which == 0) {
                     const float ss = wave_sum(x1 * x1 + x2 * x2);
                     const float rinv = 1.0f / sqrtf(ss / (float)HD + a.eps);
@@ -839,7 +1126,10 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ss += x[c][j] * x[c][j];
+            for (int j = 0; j < 8; ++j) {
+                x[c][j] *= ri;
+                ss += x[c][j] * x[c][j];
+            }
         }
         ss += __shfl_xor(ss, 16);
         ss += __shfl_xor(ss, 32);
