@@ -304,7 +304,7 @@ struct nvllm_model {
     // step buffers
     uint32_t* d_ids = nullptr;
     int *d_pos = nullptr, *d_slot = nullptr, *d_tile_row0 = nullptr, *d_tile_nrows = nullptr, *d_tile_slot = nullptr,
-        *d_last_rows = nullptr;
+        *d_last_rows = nullptr, *d_tile_order = nullptr;
     float *resid = nullptr, *slabs = nullptr, *qbuf = nullptr, *logits = nullptr, *d_maxval = nullptr, *red = nullptr;
     bf16_bits *xh = nullptr, *xl = nullptr, *xh2 = nullptr, *xl2 = nullptr, *ctxh = nullptr, *ctxl = nullptr;
     float *ssqA = nullptr, *ssqB = nullptr;  // deferred-norm partial sums of squares [groups][kFusedMaxRows]
@@ -428,10 +428,10 @@ static void free_kv(nvllm_model* m) {
     for (auto p : m->vcache) (void)hipFree(p);
     m->kcache.clear(); m->vcache.clear();
     void* ptrs[] = {m->d_block_tables, m->d_ids, m->d_pos, m->d_slot, m->d_tile_row0, m->d_tile_nrows, m->d_tile_slot,
-                    m->d_last_rows, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->xh2, m->xl2, m->ctxh, m->ctxl, m->ssqA, m->ssqB, m->d_next,
+                    m->d_last_rows, m->d_tile_order, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->xh2, m->xl2, m->ctxh, m->ctxl, m->ssqA, m->ssqB, m->d_next,
                     m->part_val, m->part_idx, m->argmax_scratch, m->attn_po, m->attn_pml, m->tap_h, m->tap_res, m->cosv, m->sinv};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    m->d_block_tables = nullptr; m->d_ids = nullptr; m->d_pos = m->d_slot = m->d_tile_row0 = m->d_tile_nrows = m->d_tile_slot = m->d_last_rows = nullptr;
+    m->d_block_tables = nullptr; m->d_ids = nullptr; m->d_pos = m->d_slot = m->d_tile_row0 = m->d_tile_nrows = m->d_tile_slot = m->d_last_rows = m->d_tile_order = nullptr;
     m->resid = m->slabs = m->qbuf = m->logits = m->d_maxval = m->red = nullptr; m->xh = m->xl = m->xh2 = m->xl2 = m->ctxh = m->ctxl = nullptr; m->ssqA = m->ssqB = nullptr; m->d_next = nullptr; m->part_val = nullptr; m->part_idx = nullptr; m->argmax_scratch = nullptr; m->attn_po = m->attn_pml = nullptr;
     m->tap_h = m->tap_res = nullptr; m->cosv = m->sinv = nullptr;
     if (m->h_stage) (void)hipHostFree(m->h_stage);
@@ -686,6 +686,7 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->d_tile_nrows, R);
     if (!rc) rc = dmalloc(ctx, &m->d_tile_slot, R);
     if (!rc) rc = dmalloc(ctx, &m->d_last_rows, (size_t)max_seqs);
+    if (!rc) rc = dmalloc(ctx, &m->d_tile_order, R);
     if (!rc) rc = dmalloc(ctx, &m->resid, R * m->H);
     if (!rc) rc = dmalloc(ctx, &m->slabs, m->slab_floats);
     if (!rc) rc = dmalloc(ctx, &m->qbuf, R * m->nh_l * m->hd);
@@ -713,7 +714,7 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->argmax_scratch, (size_t)max_seqs + 1);
     if (!rc) HIPCHK(ctx, hipMemsetAsync(m->argmax_scratch, 0, ((size_t)max_seqs + 1) * 8, ctx->stream));
     if (rc) return rc;
-    m->h_stage_bytes = (R * 6 + (size_t)max_seqs * 4) * sizeof(int) + 256;
+    m->h_stage_bytes = (R * 7 + (size_t)max_seqs * 4) * sizeof(int) + 256;
     HIPCHK(ctx, hipHostMalloc(&m->h_stage, m->h_stage_bytes, hipHostMallocDefault));
     // RoPE table: rotary_embedding.rs:56-80 (f32: inv_freq = 1/base^(2j/hd); angle = pos * inv_freq)
     m->rope_len = std::min(m->cfg.max_position_embeddings, m->max_blocks * kBlockTokens);
@@ -852,6 +853,7 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
         aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
         aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
         aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->ctxh; aa.out_lo = m->ctxl;
+        if (qt == 1) aa.tile_order = m->d_tile_order;
         if (fuse_qk) {
             aa.qkv = qa.qkv; aa.n_slabs = qa.n_slabs; aa.slab_stride = qa.slab_stride; aa.ldqkv = NQ; aa.qn = w.qn; aa.kn = w.kn;
             aa.cos = m->cosv; aa.sin = m->sinv; aa.eps = eps; aa.q_scale = qa.q_scale; aa.rn = rn;
@@ -940,6 +942,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
         aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
         aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->xh; aa.out_lo = m->xl;
+        if (qt == 1) aa.tile_order = m->d_tile_order;
         if (fuse_qk) {
             aa.qkv = qa.qkv; aa.n_slabs = qa.n_slabs; aa.slab_stride = qa.slab_stride; aa.ldqkv = NQ; aa.qn = w.qn; aa.kn = w.kn;
             aa.cos = m->cosv; aa.sin = m->sinv; aa.eps = eps; aa.q_scale = qa.q_scale;
@@ -1094,6 +1097,16 @@ static int upload_chunk(nvllm_model* m, const RowPlan& p, int r0, int R, int t0,
     memcpy(h_slot, p.slot.data() + r0, (size_t)R * 4);
     for (int i = 0; i < T; ++i) { h_t0[i] = p.tile_row0[t0 + i] - r0; h_tn[i] = p.tile_nrows[t0 + i]; h_ts[i] = p.tile_slot[t0 + i]; }
     for (size_t i = 0; i < last_local.size(); ++i) h_last[i] = last_local[i];
+    // attention load balance: q-tiles ordered by context length, longest first (stable for ties)
+    int* h_ord = h_last + m->max_seqs;
+    {
+        std::vector<int> ord(T);
+        for (int i = 0; i < T; ++i) ord[i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) {
+            return p.pos[p.tile_row0[t0 + x] + p.tile_nrows[t0 + x] - 1] > p.pos[p.tile_row0[t0 + y] + p.tile_nrows[t0 + y] - 1];
+        });
+        for (int i = 0; i < T; ++i) h_ord[i] = ord[i];
+    }
     HIPCHK(ctx, hipMemcpyAsync(m->d_ids, h_ids, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(m->d_pos, h_pos, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(m->d_slot, h_slot, (size_t)R * 4, hipMemcpyHostToDevice, s));
@@ -1102,6 +1115,7 @@ static int upload_chunk(nvllm_model* m, const RowPlan& p, int r0, int R, int t0,
     HIPCHK(ctx, hipMemcpyAsync(m->d_tile_slot, h_ts, (size_t)T * 4, hipMemcpyHostToDevice, s));
     if (!last_local.empty())
         HIPCHK(ctx, hipMemcpyAsync(m->d_last_rows, h_last, last_local.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(m->d_tile_order, h_ord, (size_t)T * 4, hipMemcpyHostToDevice, s));
     return NVLLM_OK;
 }
 
@@ -1576,6 +1590,29 @@ extern "C" int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int
         if (parts_max > kAttnMaxParts) return fail(ctx, NVLLM_EINVAL, "too many parts");
     }
     for (int i = 0; i < 3; ++i) HIPCHK(ctx, launch_attn_paged(a, B, 1, B, parts_max, s));
+    if (getenv("NVLLM_ATTN_PF")) {
+        // experiment: warm the next launch's K/V with the cache-warmer kernel first, time the attention alone
+        PrefetchRange* dr; unsigned* sink;
+        HIPCHK(ctx, t.get(&dr, (size_t)2 * nrot)); HIPCHK(ctx, t.get(&sink, 1));
+        std::vector<PrefetchRange> hr;
+        for (int r = 0; r < nrot; ++r) { hr.push_back({rk[r], cache_elems * 2}); hr.push_back({rv[r], cache_elems * 2}); }
+        HIPCHK(ctx, hipMemcpyAsync(dr, hr.data(), hr.size() * sizeof(PrefetchRange), hipMemcpyHostToDevice, s));
+        std::vector<hipEvent_t> evs(2 * iters);
+        for (auto& e : evs) HIPCHK(ctx, hipEventCreate(&e));
+        for (int i = 0; i < iters; ++i) {
+            a.kv.k = rk[i % nrot]; a.kv.v = rv[i % nrot];
+            HIPCHK(ctx, launch_prefetch_ranges(dr + 2 * (i % nrot), 2, sink, atoi(getenv("NVLLM_ATTN_PF")), s));
+            HIPCHK(ctx, hipEventRecord(evs[2 * i], s));
+            HIPCHK(ctx, launch_attn_paged(a, B, 1, B, parts_max, s));
+            HIPCHK(ctx, hipEventRecord(evs[2 * i + 1], s));
+        }
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        double tot = 0;
+        for (int i = 0; i < iters; ++i) { float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, evs[2 * i], evs[2 * i + 1])); tot += ms; }
+        for (auto& e : evs) (void)hipEventDestroy(e);
+        *us_per_call = (float)(tot * 1e3 / iters);
+        return NVLLM_OK;
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
     for (int i = 0; i < iters; ++i) {
         a.kv.k = rk[i % nrot]; a.kv.v = rv[i % nrot];

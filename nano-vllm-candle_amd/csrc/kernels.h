@@ -136,6 +136,10 @@ struct AttnArgs {
     const int* tile_nrows = nullptr;
     const int* tile_slot = nullptr;
     const int* pos = nullptr;          // [rows]
+    // load balance (decode): tile_order[rank] = tile index, longest context first; the kernel walks it forwards
+    // in even 256-workgroup rounds and backwards in odd ones so that co-resident workgroups (ids i and i+256
+    // share a CU when two fit) pair a long sequence with a short one.  nullptr = launch order.
+    const int* tile_order = nullptr;
     int nh_l = 0, gqa = 1;
     bf16_bits* out_hi = nullptr;       // [rows][nh_l*hd]
     bf16_bits* out_lo = nullptr;
@@ -216,6 +220,9 @@ hipError_t launch_bhtd_to_rows(const float* x, int B, int heads, int T, int hd, 
 // write k,v rows ([rows][kv*hd] f32) into the paged cache at (slot,pos) without norm/rope
 hipError_t launch_kv_write_plain(const float* k, const float* v, int rows, const int* pos, const int* slot,
                                  const int* block_tables, int max_blocks, KvLayout kv, hipStream_t s);
+struct PrefetchRange { const void* ptr; size_t bytes; };
+// touch every 128-byte line of the ranges (device array) so they are cache-resident for the next consumer
+hipError_t launch_prefetch_ranges(const PrefetchRange* d_ranges, int n_ranges, unsigned* sink, int blocks_x, hipStream_t s);
 // token feedback for nvllm_decode_next: ids[i] = next[i]; pos[i] += 1
 hipError_t launch_advance_decode(uint32_t* ids, const uint32_t* next, int* pos, int n, hipStream_t s);
 

@@ -1004,7 +1004,13 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, grp = lane >> 4;
-    const int tile = blockIdx.x, kh = blockIdx.y;
+    int tile = blockIdx.x;
+    const int kh = blockIdx.y;
+    if (a.tile_order) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const int rank = ((lin >> 8) & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+        tile = a.tile_order[rank];
+    }
     const int row0 = a.tile_row0[tile], nrows = a.tile_nrows[tile], slot = a.tile_slot[tile];
     const int gqa = a.gqa, tpq = 16 / gqa;
     const int kv_l = a.kv.kv_l;
@@ -1054,7 +1060,7 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
         // start this wave's first tile before the prologue unless it is the tile the new token goes into
         // (that one must be read after wave 0 has written it)
         const int kt0 = min(t_begin + wave, t_end - 1);
-        if (kt0 != (pmax >> 5)) {
+        if (false && kt0 != (pmax >> 5)) {  // A/B on MI355X: loading before the prologue is 0.8 % slower (vmcnt is in order)
             load_tile(kt0, kaA, kbA, vfA);
             pre_loaded = true;
         }
@@ -1070,87 +1076,84 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
         const int row = row0;
         const int pos = a.pos[row];
         const float* qkv_row = a.qkv + (size_t)row * a.ldqkv;
-        const float ri = rownorm_rinv_wave(a.rn, row, lane);  // deferred input norm of this row
         const bool owner = (pos >> 5) >= t_begin && (pos >> 5) < t_end;  // split-KV: one workgroup writes K/V
-        if (wave == 0 && owner) {
-            const bool act = lane < half;
-            const int blk = bt[pos >> 8];
+        // ---- every load of the prologue first, unconditionally (clamped lanes), so they overlap: a branch
+        // ---- around a load costs a full vmcnt(0) round trip each on this compiler
+        const int ln = min(lane, half - 1);
+        const float* pk = qkv_row + (size_t)(a.nh_l + kh) * HD;
+        const float* pv = qkv_row + (size_t)(a.nh_l + kv_l + kh) * HD;
+        float kx1 = 0.f, kx2 = 0.f, vx1 = 0.f, vx2 = 0.f, knw1 = 0.f, knw2 = 0.f, kc = 0.f, ks = 0.f;
+        if (wave == 0) {  // block-level branch: one wave produces the row's K/V for this kv head
+            kx1 = pk[ln]; kx2 = pk[ln + half]; vx1 = pv[ln]; vx2 = pv[ln + half];
+            knw1 = a.kn[ln]; knw2 = a.kn[ln + half];
+            kc = a.cos[(size_t)pos * half + ln]; ks = a.sin[(size_t)pos * half + ln];
+        }
+        float x[DC][8], qw[DC][8], cs[DC / 2][8], sn[DC / 2][8];
+        const int qrow_ok = my_row[0] >= 0;
+        const float* pq = qkv_row + (size_t)(qrow_ok ? my_head : 0) * HD + grp * 8;
 #pragma unroll
-            for (int which = 0; which < 2; ++which) {  // 0: k head, 1: v head
-                const float* p = qkv_row + (size_t)(a.nh_l + which * kv_l + kh) * HD;
-                float x1 = 0.f, x2 = 0.f;
-                if (act) {
-                    x1 = p[lane];
-                    x2 = p[lane + half];
-                    for (int sl = 1; sl < a.n_slabs; ++sl) {
-                        x1 += p[(size_t)sl * a.slab_stride + lane];
-                        x2 += p[(size_t)sl * a.slab_stride + lane + half];
-                    }
-                }
-                x1 *= ri;
-                x2 *= ri;
-                if (which == 0) {
-                    const float ss = wave_sum(x1 * x1 + x2 * x2);
-                    const float rinv = 1.0f / sqrtf(ss / (float)HD + a.eps);
-                    if (act) {
-                        const float n1 = (x1 * rinv) * a.kn[lane], n2 = (x2 * rinv) * a.kn[lane + half];
-                        const float c = a.cos[(size_t)pos * half + lane], sn = a.sin[(size_t)pos * half + lane];
-                        _Float16* k = reinterpret_cast<_Float16*>(a.kv.k) + (size_t)(blk * kv_l + kh) * kBlockTokens * HD;
-                        k[k_packed_offset(pos & 255, lane, HD)] = f16_sat(n1 * c - n2 * sn);
-                        k[k_packed_offset(pos & 255, lane + half, HD)] = f16_sat(n2 * c + n1 * sn);
-                    }
-                } else if (act) {
-                    _Float16* v = reinterpret_cast<_Float16*>(a.kv.v) + (size_t)(blk * kv_l + kh) * kBlockTokens * HD;
-                    v[v_packed_offset(pos & 255, lane, HD)] = f16_sat(x1);
-                    v[v_packed_offset(pos & 255, lane + half, HD)] = f16_sat(x2);
-                }
+        for (int c = 0; c < DC; ++c) {
+            *reinterpret_cast<float4*>(&x[c][0]) = *reinterpret_cast<const float4*>(pq + c * 32);
+            *reinterpret_cast<float4*>(&x[c][4]) = *reinterpret_cast<const float4*>(pq + c * 32 + 4);
+            *reinterpret_cast<float4*>(&qw[c][0]) = *reinterpret_cast<const float4*>(a.qn + c * 32 + grp * 8);
+            *reinterpret_cast<float4*>(&qw[c][4]) = *reinterpret_cast<const float4*>(a.qn + c * 32 + grp * 8 + 4);
+        }
+#pragma unroll
+        for (int c = 0; c < DC / 2; ++c) {
+            const size_t o = (size_t)pos * half + c * 32 + grp * 8;
+            *reinterpret_cast<float4*>(&cs[c][0]) = *reinterpret_cast<const float4*>(a.cos + o);
+            *reinterpret_cast<float4*>(&cs[c][4]) = *reinterpret_cast<const float4*>(a.cos + o + 4);
+            *reinterpret_cast<float4*>(&sn[c][0]) = *reinterpret_cast<const float4*>(a.sin + o);
+            *reinterpret_cast<float4*>(&sn[c][4]) = *reinterpret_cast<const float4*>(a.sin + o + 4);
+        }
+        const float ri = rownorm_rinv_wave(a.rn, row, lane);  // deferred input norm of this row
+        for (int sl = 1; sl < a.n_slabs; ++sl) {  // split-K partials of a generic QKV GEMM (rare on this path)
+            const size_t so = (size_t)sl * a.slab_stride;
+            if (wave == 0) { kx1 += pk[so + ln]; kx2 += pk[so + ln + half]; vx1 += pv[so + ln]; vx2 += pv[so + ln + half]; }
+#pragma unroll
+            for (int c = 0; c < DC; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[c][j] += pq[so + c * 32 + j];
+        }
+        // ---- K / V of the new token (wave 0 of the owning workgroup)
+        if (wave == 0) {
+            const bool act = lane < half;
+            kx1 = act ? kx1 * ri : 0.f; kx2 = act ? kx2 * ri : 0.f;
+            const float kss = wave_sum(kx1 * kx1 + kx2 * kx2);
+            const float krinv = 1.0f / sqrtf(kss / (float)HD + a.eps);
+            if (owner && act) {
+                const int blk = bt[pos >> 8];
+                const float n1 = (kx1 * krinv) * knw1, n2 = (kx2 * krinv) * knw2;
+                _Float16* k = reinterpret_cast<_Float16*>(a.kv.k) + (size_t)(blk * kv_l + kh) * kBlockTokens * HD;
+                k[k_packed_offset(pos & 255, lane, HD)] = f16_sat(n1 * kc - n2 * ks);
+                k[k_packed_offset(pos & 255, lane + half, HD)] = f16_sat(n2 * kc + n1 * ks);
+                _Float16* v = reinterpret_cast<_Float16*>(a.kv.v) + (size_t)(blk * kv_l + kh) * kBlockTokens * HD;
+                v[v_packed_offset(pos & 255, lane, HD)] = f16_sat(vx1 * ri);
+                v[v_packed_offset(pos & 255, lane + half, HD)] = f16_sat(vx2 * ri);
             }
             // make the new token visible to the other waves of THIS workgroup (same CU: write-through L1 -> L2)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        // q rows of this lane: dims c*32 + grp*8 + j; RoPE pairs chunk c with c + DC/2 (same lane)
-        float x[DC][8];
+        // ---- q: deferred input norm, RMSNorm over head_dim, RoPE (chunk c pairs with c + DC/2 in the same lane)
         float ss = 0.f;
 #pragma unroll
-        for (int c = 0; c < DC; ++c) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[c][j] = 0.f;
-            if (my_row[0] >= 0) {
-                const float* p = qkv_row + (size_t)my_head * HD + c * 32 + grp * 8;
-                for (int sl = 0; sl < a.n_slabs; ++sl) {
-                    const float4 u = *reinterpret_cast<const float4*>(p + (size_t)sl * a.slab_stride);
-                    const float4 w = *reinterpret_cast<const float4*>(p + (size_t)sl * a.slab_stride + 4);
-                    x[c][0] += u.x; x[c][1] += u.y; x[c][2] += u.z; x[c][3] += u.w;
-                    x[c][4] += w.x; x[c][5] += w.y; x[c][6] += w.z; x[c][7] += w.w;
-                }
-            }
+        for (int c = 0; c < DC; ++c)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                x[c][j] *= ri;
+                x[c][j] = qrow_ok ? x[c][j] * ri : 0.f;
                 ss += x[c][j] * x[c][j];
             }
-        }
         ss += __shfl_xor(ss, 16);
         ss += __shfl_xor(ss, 32);
         const float rinv = 1.0f / sqrtf(ss / (float)HD + a.eps);
 #pragma unroll
         for (int c = 0; c < DC / 2; ++c) {
-            float cs[8], sn[8], w1[8], w2[8];
-            const int d0 = c * 32 + grp * 8;  // index inside the half
-            *reinterpret_cast<float4*>(cs) = *reinterpret_cast<const float4*>(a.cos + (size_t)pos * half + d0);
-            *reinterpret_cast<float4*>(cs + 4) = *reinterpret_cast<const float4*>(a.cos + (size_t)pos * half + d0 + 4);
-            *reinterpret_cast<float4*>(sn) = *reinterpret_cast<const float4*>(a.sin + (size_t)pos * half + d0);
-            *reinterpret_cast<float4*>(sn + 4) = *reinterpret_cast<const float4*>(a.sin + (size_t)pos * half + d0 + 4);
-            *reinterpret_cast<float4*>(w1) = *reinterpret_cast<const float4*>(a.qn + d0);
-            *reinterpret_cast<float4*>(w1 + 4) = *reinterpret_cast<const float4*>(a.qn + d0 + 4);
-            *reinterpret_cast<float4*>(w2) = *reinterpret_cast<const float4*>(a.qn + half + d0);
-            *reinterpret_cast<float4*>(w2 + 4) = *reinterpret_cast<const float4*>(a.qn + half + d0 + 4);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float n1 = (x[c][j] * rinv) * w1[j], n2 = (x[c + DC / 2][j] * rinv) * w2[j];
-                const float y1 = (n1 * cs[j] - n2 * sn[j]) * a.q_scale;
-                const float y2 = (n2 * cs[j] + n1 * sn[j]) * a.q_scale;
+                const float n1 = (x[c][j] * rinv) * qw[c][j], n2 = (x[c + DC / 2][j] * rinv) * qw[c + DC / 2][j];
+                const float y1 = (n1 * cs[c][j] - n2 * sn[c][j]) * a.q_scale;
+                const float y2 = (n2 * cs[c][j] + n1 * sn[c][j]) * a.q_scale;
                 const _Float16 h1 = (_Float16)y1, h2 = (_Float16)y2;
                 qh[0][c][j] = h1;
                 ql[0][c][j] = (_Float16)(y1 - (float)h1);
@@ -1639,6 +1642,31 @@ __global__ void advance_decode_kernel(uint32_t* ids, const uint32_t* next, int* 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { ids[i] = next[i]; pos[i] += 1; }
 }
+// ---------------------------------------------------------------------------------------------------
+// Cache warmer: touch a list of byte ranges so they sit in the Infinity Cache (MALL) when the consumer
+// kernel arrives.  Runs on a side stream while latency-bound kernels leave HBM idle.  ranges[i] = {ptr, bytes}.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) prefetch_ranges_kernel(const PrefetchRange* __restrict__ ranges, int n_ranges,
+                                                              unsigned* __restrict__ sink) {
+    unsigned acc = 0;
+    for (int r = blockIdx.y; r < n_ranges; r += gridDim.y) {
+        const uint4* p = reinterpret_cast<const uint4*>(ranges[r].ptr);
+        const size_t n16 = ranges[r].bytes >> 4;
+        // one 16-byte load per 128-byte line is enough to pull the line in; consecutive lanes take consecutive lines
+        for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n16; i += (size_t)gridDim.x * blockDim.x * 8) {
+            const uint4 v = p[i];
+            acc ^= v.x;
+        }
+    }
+    if (acc == 0x9e3779b9u && sink) *sink = acc;  // never true in practice; keeps the loads alive
+}
+hipError_t launch_prefetch_ranges(const PrefetchRange* d_ranges, int n_ranges, unsigned* sink, int blocks_x, hipStream_t s) {
+    if (n_ranges <= 0) return hipSuccess;
+    dim3 grid(std::max(1, blocks_x), std::min(n_ranges, 64));
+    prefetch_ranges_kernel<<<grid, 256, 0, s>>>(d_ranges, n_ranges, sink);
+    return hipGetLastError();
+}
+
 hipError_t launch_advance_decode(uint32_t* ids, const uint32_t* next, int* pos, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     advance_decode_kernel<<<(n + 255) / 256, 256, 0, s>>>(ids, next, pos, n);
