@@ -164,7 +164,7 @@ def main():
     if dom == "attn":
         # algorithmic bytes of one launch = every attended token's K and V of this layer, read once
         dom_bytes = float(np.mean(attn_ctx)) * kv_layer
-        dom_name = "attn_paged_kernel<128,1>"
+        dom_name = "attn_paged_kernel<128, 1, 4, true>"
     elif dom == "lm_head":
         dom_bytes = float(cfg.hidden_size * (cfg.vocab_size // world) * 2)
         dom_name = "gemm_kernel (LM head)"
@@ -177,6 +177,14 @@ def main():
     step_gbs = (bytes_total / a.steps) / (ev_ms / a.steps * 1e-3) / 1e9
     roof = {"bound": "hbm", "kernel": dom_name, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "avg_launch_us": dom_ms / max(dom_n, 1) * 1e3}
+    # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, gfx950 x2 correction applied):
+    # a separate profiled run of this same command, so it is quoted with that run's own algorithmic bytes
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path)).get(dom_name)
+        if pmc:
+            roof["traffic"] = pmc["fetch_bytes_per_launch"]
+            roof["traffic_run_algorithmic_bytes"] = pmc["algorithmic_bytes_per_launch"]
     if dom_bytes is not None:
         roof["achieved"] = dom_bytes / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS

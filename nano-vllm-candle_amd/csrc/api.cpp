@@ -831,14 +831,13 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
         {   // QKV projection: whole-K row-parallel kernel (one f32 result, no slabs) when the shape allows
             RowParArgs rq;
             rq.xh = m->xh; rq.xl = m->xl; rq.ldx = H; rq.out = m->slabs; rq.M = R;
-            hipError_t e = launch_gemm_rowpar(rq, w.qkv, 2, s);
-            if (e == hipErrorNotSupported) {
+            if (gemm_rowpar_ok(NQ, H, 2, R)) {
+                PROF(m, PROF_GEMM, launch_gemm_rowpar(rq, w.qkv, 2, s));
+                qa.n_slabs = 1;
+            } else {
                 GemmPlan pq = plan_gemm(R, NQ, H, 8);
                 PROF(m, PROF_GEMM, launch_gemm(pq, m->xh, m->xl, H, w.qkv, m->slabs, R, s));
                 qa.n_slabs = pq.n_split;
-            } else {
-                HIPCHK(ctx, e);
-                qa.n_slabs = 1;
             }
         }
         qa.qkv = m->slabs; qa.slab_stride = (int64_t)R * NQ; qa.qn = w.qn; qa.kn = w.kn; qa.eps = eps;
@@ -874,13 +873,12 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
         {
             RowParArgs rg;
             rg.xh = m->xh; rg.xl = m->xl; rg.ldx = H; rg.oh = m->xh2; rg.ol = m->xl2; rg.M = R; rg.rn = rn;
-            hipError_t e = launch_gemm_rowpar(rg, w.gu, 1, s);
-            if (e == hipErrorNotSupported) {
+            if (gemm_rowpar_ok(2 * m->I_l, H, 1, R)) {
+                PROF(m, PROF_GEMM, launch_gemm_rowpar(rg, w.gu, 1, s));
+            } else {
                 GemmPlan pg = plan_gemm_swiglu(R, 2 * m->I_l, H);
                 gemm_set_rownorm(&rn);
                 PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, s));
-            } else {
-                HIPCHK(ctx, e);
             }
         }
         // down_proj + residual + next layer's input norm prep (qwen3.rs:326, next layer :378; last layer: final norm :497)

@@ -186,6 +186,7 @@ struct RowParArgs {
     RowNorm rn;
 };
 bool gemm_rowpar_supported(int N, int K);
+bool gemm_rowpar_ok(int N, int K, int epi, int M);
 int gemm_rowpar_groups(int N, int K);
 // epi: 0 residual + next-norm prep, 1 SwiGLU, 2 plain f32 output
 hipError_t launch_gemm_rowpar(const RowParArgs& a, const PackedW& w, int epi, hipStream_t s);

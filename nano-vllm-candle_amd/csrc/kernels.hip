@@ -616,8 +616,9 @@ __global__ void __launch_bounds__(NWN * NWK * 64) gemm_rowpar_kernel(RowParArgs 
     constexpr int NBUF = PH > 1 ? 2 : 1;      // x images resident at once
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     uint4* lds_x = reinterpret_cast<uint4*>(smem_raw);                                  // [NBUF][2 planes][KTP][64]
-    f32x4* red = reinterpret_cast<f32x4*>(smem_raw + (size_t)NBUF * 2 * KTP * 1024);    // [NW][64]
-    float* sred = reinterpret_cast<float*>(smem_raw + (size_t)NBUF * 2 * KTP * 1024 + (size_t)NW * 1024);  // [NWN][16] / rinv partials [4][16]
+    // the cross-wave reduction buffer aliases the x image (dead after the last compute; one extra barrier)
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                                    // [NW][64]
+    float* sred = reinterpret_cast<float*>(smem_raw + (size_t)NBUF * 2 * KTP * 1024);   // [NWN][16] / rinv partials [4][16]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, grp = lane >> 4;
     const int wn = wave / NWK, wk = wave % NWK;
@@ -680,6 +681,7 @@ __global__ void __launch_bounds__(NWN * NWK * 64) gemm_rowpar_kernel(RowParArgs 
         }
         if (p + 1 < PH && p + 2 < PH + 1 && p >= 1) __syncthreads();  // phase p+1 (staged after the first barrier) landed
     }
+    __syncthreads();  // every wave is done reading the x image: it becomes the reduction buffer
     red[(size_t)wave * 64 + lane] = acc;
     __syncthreads();
     if (wk == 0) {
@@ -715,11 +717,13 @@ __global__ void __launch_bounds__(NWN * NWK * 64) gemm_rowpar_kernel(RowParArgs 
         }
     } else if constexpr (EPI == 1) {
         // SwiGLU: n-tile 0 of the workgroup = gate, n-tile 1 = up of the same 16 features (interleaved weight)
-        static_assert(EPI != 1 || NWN == 2, "SwiGLU epilogue pairs two n-tiles");
-        if (wk == 0 && wn == 1) red[(size_t)(NWK) * 64 + lane] = acc;  // own slot: nobody else reads it before the barrier
+        static_assert(EPI != 1 || (NWN % 2 == 0), "SwiGLU epilogue pairs two n-tiles");
+        // odd n-tile waves (up) park their sums in their own slot; the even (gate) wave of the pair finishes
+        if (wk == 0 && (wn & 1)) red[(size_t)(wn * NWK) * 64 + lane] = acc;
         __syncthreads();
-        if (wave == 0 && row < M && ((int)blockIdx.x * 2 + 1) < ntiles) {
-            const f32x4 up = red[(size_t)(NWK) * 64 + lane];
+        const int pair = (int)blockIdx.x * (NWN / 2) + (wn >> 1);  // activation feature tile
+        if (wk == 0 && !(wn & 1) && row < M && (pair * 2 + 1) < ntiles) {
+            const f32x4 up = red[(size_t)((wn + 1) * NWK) * 64 + lane];
             const float ri = rownorm_rinv_lds<16>(a.rn, sred, l15);
             const int I = N >> 1;
             uint16_t h[4], l[4];
@@ -728,7 +732,7 @@ __global__ void __launch_bounds__(NWN * NWK * 64) gemm_rowpar_kernel(RowParArgs 
                 const float g = acc[r] * ri, u = up[r] * ri;
                 split_bf16((g / (1.0f + __expf(-g))) * u, h[r], l[r]);
             }
-            const size_t o = (size_t)row * I + (size_t)blockIdx.x * 16 + grp * 4;
+            const size_t o = (size_t)row * I + (size_t)pair * 16 + grp * 4;
             *reinterpret_cast<uint2*>(a.oh + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
             *reinterpret_cast<uint2*>(a.ol + o) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
         }
@@ -739,29 +743,37 @@ __global__ void __launch_bounds__(NWN * NWK * 64) gemm_rowpar_kernel(RowParArgs 
 }
 
 struct RowParShape { int nwn, nwk, tpw, ph; };
-static bool rowpar_shape(int N, int K, RowParShape& sh) {
+static bool rowpar_shape(int N, int K, int epi, int M, RowParShape& sh) {
     if (N % 16 || K % 32) return false;
-    const int KT = K / 32;
+    const int KT = K / 32, ntiles = N / 16, mblocks = (std::max(M, 1) + 15) / 16;
     // fewest phases whose x image fits 64 KiB (KTP <= 32 k-tiles), most k-slices per workgroup first
     static const int tpws[] = {8, 12, 16};
     for (int ph = 1; ph <= 4; ++ph)
         for (int nwk : {4, 2, 1})
             for (int tpw : tpws) {
                 if (ph * nwk * tpw != KT || nwk * tpw > 32) continue;
-                const int nwn = (N / 16) % 2 == 0 ? 2 : 1;
+                int nwn = ntiles % 2 == 0 ? 2 : 1;
+                // wide projections (QKV, gate/up): 4 n-tiles per workgroup halves the x re-staging and keeps the
+                // whole grid resident in one round (2 workgroups of 16 waves per CU) -- only where it still
+                // leaves >= 192 workgroups
+                if (epi != 0 && ph == 1 && nwk == 4 && tpw == 8 && ntiles % 4 == 0 && (ntiles / 4) * mblocks >= 192) nwn = 4;
                 if ((2 * tpw) % nwn) continue;
                 sh = {nwn, nwk, tpw, ph};
                 return true;
             }
     return false;
 }
-bool gemm_rowpar_supported(int N, int K) { RowParShape sh; return rowpar_shape(N, K, sh); }
-int gemm_rowpar_groups(int N, int K) { RowParShape sh; if (!rowpar_shape(N, K, sh)) return 0; return (N / 16 + sh.nwn - 1) / sh.nwn; }
+bool gemm_rowpar_supported(int N, int K) { RowParShape sh; return rowpar_shape(N, K, 0, 64, sh); }
+bool gemm_rowpar_ok(int N, int K, int epi, int M) {
+    RowParShape sh;
+    return rowpar_shape(N, K, epi, M, sh) && !(epi == 1 && sh.nwn % 2);
+}
+int gemm_rowpar_groups(int N, int K) { RowParShape sh; if (!rowpar_shape(N, K, 0, 64, sh)) return 0; return (N / 16 + sh.nwn - 1) / sh.nwn; }
 
 template <int NWN, int NWK, int TPW, int PH, int EPI>
 static hipError_t rowpar_launch_t(const RowParArgs& a, const PackedW& w, hipStream_t s) {
     constexpr int NW = NWN * NWK, KTP = NWK * TPW, NBUF = PH > 1 ? 2 : 1;
-    const size_t lds = (size_t)NBUF * 2 * KTP * 1024 + (size_t)NW * 1024 + 4 * 16 * 4;
+    const size_t lds = std::max((size_t)NBUF * 2 * KTP * 1024, (size_t)NW * 1024) + 4 * 16 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowpar_kernel<NWN, NWK, TPW, PH, EPI>),
@@ -782,6 +794,7 @@ static hipError_t rowpar_dispatch(const RowParShape& sh, const RowParArgs& a, co
     NVLLM_RP(NWN_, 1, 8, PH_) NVLLM_RP(NWN_, 1, 12, PH_) NVLLM_RP(NWN_, 1, 16, PH_)
     NVLLM_RP_PH(2, 1) NVLLM_RP_PH(2, 2) NVLLM_RP_PH(2, 3) NVLLM_RP_PH(2, 4)
     if constexpr (EPI != 1) { NVLLM_RP_PH(1, 1) NVLLM_RP_PH(1, 2) NVLLM_RP_PH(1, 3) NVLLM_RP_PH(1, 4) }
+    if constexpr (EPI != 0) { NVLLM_RP(4, 4, 8, 1) }
 #undef NVLLM_RP_PH
 #undef NVLLM_RP
     return hipErrorNotSupported;
@@ -789,8 +802,8 @@ static hipError_t rowpar_dispatch(const RowParShape& sh, const RowParArgs& a, co
 
 hipError_t launch_gemm_rowpar(const RowParArgs& a, const PackedW& w, int epi, hipStream_t s) {
     RowParShape sh;
-    if (!rowpar_shape(w.N, w.K, sh)) return hipErrorNotSupported;
-    if (epi == 1 && sh.nwn != 2) return hipErrorNotSupported;
+    if (!rowpar_shape(w.N, w.K, epi, a.M, sh)) return hipErrorNotSupported;
+    if (epi == 1 && sh.nwn % 2) return hipErrorNotSupported;
     if (a.M <= 0) return hipSuccess;
     if (epi == 0) return rowpar_dispatch<0>(sh, a, w, s);
     if (epi == 1) return rowpar_dispatch<1>(sh, a, w, s);
