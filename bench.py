@@ -112,8 +112,13 @@ def main():
     model.kv_alloc(num_blocks=blocks, max_seqs=a.batch, max_batched_tokens=4096)
     seq_ids = list(range(a.batch))
 
-    # prefill (untimed), in groups bounded like the reference scheduler's max_num_batched_tokens
+    # prefill (not part of `value`; timed separately for the MFMA-side statement), chunked by max_batched_tokens
+    torch.cuda.synchronize()
+    tp0 = time.perf_counter()
     model.step(seq_ids, prompts, is_prefill=True)
+    torch.cuda.synchronize()
+    prefill_s = time.perf_counter() - tp0
+    prefill_tokens = sum(len(p) for p in prompts)
     ctx_lens = np.array([len(p) + 1 for p in prompts], dtype=np.int64)  # tokens attended by the next decode step
 
     def barrier():
@@ -158,9 +163,14 @@ def main():
         kern[kind] = model.profile_read()
     model.profile_kernel(None)
     per_step = {k: ms / pass_steps for k, (ms, n) in kern.items()}
-    dom = max(per_step, key=per_step.get)
-    dom_ms, dom_n = kern[dom]
     kv_layer = model.kv_bytes_per_token // cfg.num_hidden_layers  # K+V bytes of one token in one layer (this rank)
+    # dominant kernel = the class that moves the most algorithmic bytes per step (the path is HBM-bound); the
+    # HIP-event brackets add ~2 us per launch, so ranking by bracketed time would favour many-launch classes
+    lm_bytes = cfg.hidden_size * (cfg.vocab_size // world) * 2
+    step_bytes_by_kind = {"attn": float(np.mean(attn_ctx)) * kv_layer * cfg.num_hidden_layers,
+                          "gemm": float(model.weight_bytes - lm_bytes), "lm_head": float(lm_bytes)}
+    dom = max(step_bytes_by_kind, key=step_bytes_by_kind.get)
+    dom_ms, dom_n = kern[dom]
     if dom == "attn":
         # algorithmic bytes of one launch = every attended token's K and V of this layer, read once
         dom_bytes = float(np.mean(attn_ctx)) * kv_layer
@@ -203,6 +213,13 @@ def main():
                           "event_ms_per_step": ev_ms / a.steps},
         "kernel_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
     }
+    # prefill is the MFMA-bound side: algorithmic flops = 2 * matmul params * tokens (attention excluded);
+    # the kernels issue 2x that on the MFMA pipe because activations are bf16 hi + lo
+    mm_params = (model.weight_bytes * world) / 2
+    pf_tflops = 2.0 * mm_params * prefill_tokens / prefill_s / 1e12
+    out["prefill"] = {"tokens": prefill_tokens, "ms": prefill_s * 1e3, "tokens_per_s": prefill_tokens / prefill_s,
+                      "algorithmic_tflops": pf_tflops, "mfma_peak_tflops_bf16_dense": 2500.0 * world,
+                      "frac_of_mfma_peak": pf_tflops / (2500.0 * world), "note": "first call, includes one-time setup"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:  # reported at N=1 only (driver contract)
         out["cpu_baseline"] = cpu_baseline(cfg, prompts, a.cpu_seqs, a.seed)
     if rank == 0:
