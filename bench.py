@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W [--model qwen3-0.6b] [--batch 64]
 
 One "step" = one decode step of the whole batch through the HIP path (libnvllm_amd.so, C ABI):
-every live sequence gets one new token; the greedy ids come back to the host every step, as the
-reference's LLMEngine.step consumes them (src/engine/llm_engine.rs:239-264).
+every live sequence gets one new token; the greedy ids of every step come back to the host (the reference's
+LLMEngine.step consumes them, src/engine/llm_engine.rs:239-264), one step late: the loop keeps one step
+enqueued ahead (nvllm_decode_enqueue / nvllm_decode_collect).
 
 N = 1  Qwen3-0.6B shapes, 64 live sequences (BASELINE.json configs[2] steady state: prompt lengths
        uniform 64..512, seed 0), synthetic bf16 weights generated in HBM, prefill untimed.
@@ -133,10 +134,16 @@ def main():
     bytes_total = 0
     ctx.timer_start()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        model.decode_next()          # ids of all sequences come back to the host here
+    # pipelined decode: step t+1 is enqueued before step t's ids are collected, so the GPU never waits for the
+    # host between steps; every step's ids still reach the host (asynchronous scheduling, one step late)
+    model.decode_enqueue()
+    bytes_total += model.last_step_bytes
+    for _ in range(a.steps - 1):
+        model.decode_enqueue()
         bytes_total += model.last_step_bytes
-        ctx_lens += 1
+        model.decode_collect()
+    model.decode_collect()
+    ctx_lens += a.steps
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0

@@ -132,6 +132,12 @@ int nvllm_step(nvllm_model* m, int n_seqs, const int64_t* seq_ids, const uint32_
  * produced by that call.  No host<->device traffic besides next_ids (nullable). */
 int nvllm_decode_next(nvllm_model* m, uint32_t* next_ids);
 
+/* Pipelined form of nvllm_decode_next: enqueue puts one more decode step on the stream and returns at once (up to 4
+ * in flight); collect waits for the OLDEST enqueued step and returns its ids.  Enqueueing step t+1 before collecting
+ * step t hides the host round trip between steps. */
+int nvllm_decode_enqueue(nvllm_model* m);
+int nvllm_decode_collect(nvllm_model* m, uint32_t* next_ids);
+
 /* per-decode-step algorithmic HBM bytes of the LAST step on this rank:
  * weight_bytes + sum_seq ctx*kv_tok + n_seqs*kv_tok (+ 4*n_seqs*vocab when logits left the device) */
 int64_t nvllm_last_step_bytes(const nvllm_model* m);

@@ -63,6 +63,8 @@ _SIGS = {
     "nvllm_step": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_uint32)),
                              C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "nvllm_decode_next": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
+    "nvllm_decode_enqueue": (C.c_int, [_vp]),
+    "nvllm_decode_collect": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "nvllm_last_step_bytes": (C.c_int64, [_vp]),
     "nvllm_profile_kernel": (C.c_int, [_vp, C.c_int]),
     "nvllm_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

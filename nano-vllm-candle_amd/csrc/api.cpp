@@ -267,6 +267,7 @@ static int dmalloc(nvllm_ctx* c, T** p, size_t count) {
 // model
 // ---------------------------------------------------------------------------------------------------
 constexpr int kFusedMaxRows = 128;  // the fused decode path (deferred norms, row-parallel epilogues) handles up to this many rows
+constexpr int kMaxPending = 4;   // decode steps that may be enqueued before one is collected
 constexpr int kAttnMaxParts = 64;  // split-KV partitions per sequence (partition grows with context beyond 8K)
 
 struct LayerW {
@@ -329,6 +330,11 @@ struct nvllm_model {
     std::vector<int> last_lens;
     int64_t last_bytes = 0;
     bool decode_resident = false;  // device metadata describes a pure-decode batch == last_ids
+    // pipelined decode (nvllm_decode_enqueue / _collect)
+    uint32_t* pin_ids = nullptr;
+    hipEvent_t pend_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<int> pending;
+    int pend_next = 0;
 
     // per-kernel-class HIP-event timing (bench roofline leg); 0 = off
     int prof_kind = 0;
@@ -444,6 +450,8 @@ extern "C" int nvllm_model_destroy(nvllm_model* m) {
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     free_kv(m);
+    if (m->pin_ids) (void)hipHostFree(m->pin_ids);
+    for (hipEvent_t e : m->pend_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     (void)hipFree(m->embed); (void)hipFree(m->lm_head.data); (void)hipFree(m->norm);
     for (auto& w : m->layers) {
@@ -1123,6 +1131,7 @@ extern "C" int nvllm_step(nvllm_model* m, int n_seqs, const int64_t* seq_ids, co
     nvllm_ctx* ctx = m->ctx;
     if (!m->finalized) return fail(ctx, NVLLM_ESTATE, "nvllm_model_finalize not called");
     if (!m->num_blocks) return fail(ctx, NVLLM_ESTATE, "nvllm_kv_alloc not called");
+    if (!m->pending.empty()) return fail(ctx, NVLLM_ESTATE, "collect the enqueued decode steps first");
     if (n_seqs == 0) return NVLLM_OK;  // llm_engine.rs:147-149
     if (n_seqs < 0 || !seq_ids || !tokens || !lens) return fail(ctx, NVLLM_EINVAL, "bad step arguments");
     if (n_seqs > m->max_seqs) return fail(ctx, NVLLM_EINVAL, "%d sequences > max_seqs %d", n_seqs, m->max_seqs);
@@ -1212,8 +1221,8 @@ extern "C" int nvllm_step(nvllm_model* m, int n_seqs, const int64_t* seq_ids, co
     return NVLLM_OK;
 }
 
-extern "C" int nvllm_decode_next(nvllm_model* m, uint32_t* next_ids) {
-    if (!m) return NVLLM_EINVAL;
+// enqueue one more decode step for the resident batch (no host sync): everything up to the device arg-max
+static int decode_core(nvllm_model* m) {
     nvllm_ctx* ctx = m->ctx;
     const int n = (int)m->last_ids.size();
     if (n == 0) return fail(ctx, NVLLM_ESTATE, "no previous step to continue");
@@ -1254,8 +1263,6 @@ extern "C" int nvllm_decode_next(nvllm_model* m, uint32_t* next_ids) {
     set_attn_split(m, n, *std::max_element(m->last_lens.begin(), m->last_lens.end()) + 1);
     int rc = forward_chunk(m, n, n, 1, n, 0);
     if (rc) return rc;
-    rc = finish_logits(m, n, next_ids, nullptr);
-    if (rc) return rc;
     int64_t kv_tokens = 0;
     for (int i = 0; i < n; ++i) {
         m->last_lens[i] += 1;
@@ -1263,6 +1270,53 @@ extern "C" int nvllm_decode_next(nvllm_model* m, uint32_t* next_ids) {
         kv_tokens += m->last_lens[i];
     }
     m->last_bytes = nvllm_model_weight_bytes(m) + kv_tokens * nvllm_kv_bytes_per_token(m);
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_decode_next(nvllm_model* m, uint32_t* next_ids) {
+    if (!m) return NVLLM_EINVAL;
+    if (!m->pending.empty()) return fail(m->ctx, NVLLM_ESTATE, "collect the enqueued decode steps first");
+    int rc = decode_core(m);
+    if (rc) return rc;
+    return finish_logits(m, (int)m->last_ids.size(), next_ids, nullptr);
+}
+
+// Pipelined form: enqueue returns as soon as the step is on the stream (its ids travel to a pinned slot behind
+// an event); collect waits for the OLDEST enqueued step.  Keeping one step in flight hides the host round trip
+// (the reference's engine consumes ids once per step, llm_engine.rs:239-242; asynchronous scheduling sees them one
+// step late).  Tensor-parallel contexts fall back to a synchronous step inside enqueue.
+extern "C" int nvllm_decode_enqueue(nvllm_model* m) {
+    if (!m) return NVLLM_EINVAL;
+    nvllm_ctx* ctx = m->ctx;
+    const int n = (int)m->last_ids.size();
+    if ((int)m->pending.size() >= kMaxPending) return fail(ctx, NVLLM_ESTATE, "too many decode steps in flight (max %d)", kMaxPending);
+    int rc = decode_core(m);
+    if (rc) return rc;
+    if (!m->pin_ids) {
+        HIPCHK(ctx, hipHostMalloc((void**)&m->pin_ids, (size_t)kMaxPending * m->max_seqs * 4, hipHostMallocDefault));
+        for (int i = 0; i < kMaxPending; ++i) HIPCHK(ctx, hipEventCreateWithFlags(&m->pend_ev[i], hipEventDisableTiming));
+    }
+    const int slot = m->pend_next;
+    m->pend_next = (m->pend_next + 1) % kMaxPending;
+    uint32_t* dst = m->pin_ids + (size_t)slot * m->max_seqs;
+    if (ctx->tp_size > 1) {
+        rc = finish_logits(m, n, dst, nullptr);  // synchronous under TP (host picks the best shard)
+        if (rc) return rc;
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(dst, m->d_next, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipEventRecord(m->pend_ev[slot], ctx->stream));
+    m->pending.push_back(slot);
+    return NVLLM_OK;
+}
+
+extern "C" int nvllm_decode_collect(nvllm_model* m, uint32_t* next_ids) {
+    if (!m) return NVLLM_EINVAL;
+    if (m->pending.empty()) return fail(m->ctx, NVLLM_ESTATE, "no enqueued decode step");
+    const int slot = m->pending.front();
+    m->pending.erase(m->pending.begin());
+    HIPCHK(m->ctx, hipEventSynchronize(m->pend_ev[slot]));
+    if (next_ids) memcpy(next_ids, m->pin_ids + (size_t)slot * m->max_seqs, m->last_ids.size() * 4);
     return NVLLM_OK;
 }
 

@@ -355,10 +355,12 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
         }
     }
     if constexpr (MODE == 2) {
-        static_assert(MODE != 2 || NT == 2, "SwiGLU epilogue needs the gate and the up tile in one wave");
+        static_assert(MODE != 2 || NT % 2 == 0, "SwiGLU epilogue needs gate and up tiles of a feature in one wave");
         const int I = N >> 1;
-        if (nt0 < ntiles) {
-            const int f0 = (nt0 >> 1) * 16 + grp * 4;  // activation feature of acc[.][.][0]
+#pragma unroll
+        for (int pr = 0; pr < NT / 2; ++pr) {
+            if (nt0 + 2 * pr + 1 >= ntiles) continue;
+            const int f0 = ((nt0 >> 1) + pr) * 16 + grp * 4;  // activation feature of acc[.][.][0]
 #pragma unroll
             for (int b = 0; b < MT; ++b) {
                 const int row = m0 + b * 16 + l15;
@@ -367,7 +369,7 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
                     uint16_t h[4], l[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float g = acc[0][b][r] * ri, u = acc[NT - 1][b][r] * ri;
+                        const float g = acc[2 * pr][b][r] * ri, u = acc[2 * pr + 1][b][r] * ri;
                         split_bf16((g / (1.0f + __expf(-g))) * u, h[r], l[r]);
                     }
                     *reinterpret_cast<uint2*>(act_hi + (size_t)row * I + f0) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
@@ -480,6 +482,9 @@ GemmPlan plan_gemm(int M, int N, int K, int max_split) {
     const int ntiles = N / 16;
     p.nw = 4;
     p.nt = ((int64_t)ntiles * rowblocks >= 2048) ? 2 : 1;
+    // prefill (MFMA-bound): 128 x 256 output tile per workgroup, 128 MFMAs per wave between barriers so the
+    // next chunk's LDS-DMA hides behind the matrix pipe; 64 KiB of LDS -> two workgroups per CU
+    if (M >= 256 && ntiles % 4 == 0) p.nt = 4;
     const int KT = K / 32;
     const int64_t groups = (int64_t)((ntiles + p.nt * p.nw - 1) / (p.nt * p.nw)) * rowblocks;
     int ns = 1;
@@ -528,6 +533,7 @@ static hipError_t gemm_dispatch_nw(const GemmPlan& p, const bf16_bits* xh, const
     NVLLM_GEMM_CASE(2, 2, 4)
     NVLLM_GEMM_CASE(4, 2, 4)
     NVLLM_GEMM_CASE(8, 2, 2)
+    if constexpr (NW == 4) { NVLLM_GEMM_CASE(8, 4, 2) }  // prefill tile: 128 rows x 256 features per workgroup
 #undef NVLLM_GEMM_CASE
     return hipErrorInvalidValue;
 }
@@ -562,7 +568,7 @@ hipError_t launch_gemm_argmax(const GemmPlan& p, const bf16_bits* xh, const bf16
 // gate/up GEMM with the SwiGLU epilogue; w = interleaved gate_up [2I][K]; act planes [M][I]
 hipError_t launch_gemm_swiglu(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
                               int M, bf16_bits* act_hi, bf16_bits* act_lo, hipStream_t s) {
-    if (p.nt != 2 || p.n_split != 1 || !act_hi || !act_lo) return hipErrorInvalidValue;
+    if (p.nt % 2 || p.n_split != 1 || !act_hi || !act_lo) return hipErrorInvalidValue;
     GemmExtra x;
     x.act_hi = act_hi; x.act_lo = act_lo;
     x.rn = g_next_rownorm; g_next_rownorm = RowNorm{};
@@ -578,6 +584,7 @@ GemmPlan plan_gemm_swiglu(int M, int N2, int K) {
         p.mt = 1; p.kc = 4; p.nw = 2;
     } else {
         p.nw = 4;
+        if (M >= 256 && (N2 / 16) % 4 == 0) p.nt = 4;
     }
     set_split(p, K / 32, 1);
     return p;

@@ -239,6 +239,16 @@ class Qwen3ForCausalLM:
                    self.ctx.h)
         return buf
 
+    def decode_enqueue(self):
+        """put one more decode step on the stream without waiting (pipelined decode)"""
+        _lib.check(_lib.lib().nvllm_decode_enqueue(self.h), self.ctx.h)
+
+    def decode_collect(self):
+        """ids of the oldest enqueued decode step"""
+        buf = np.empty(max(getattr(self, "max_seqs", 1), 1), np.uint32)
+        _lib.check(_lib.lib().nvllm_decode_collect(self.h, buf.ctypes.data_as(C.POINTER(C.c_uint32))), self.ctx.h)
+        return buf
+
     PROF_KINDS = {"attn": 1, "gemm": 2, "norm": 3, "qk": 4, "silu": 5, "lm_head": 6}
 
     def profile_kernel(self, kind):

@@ -72,6 +72,22 @@ def test_decode_next_device_feedback_equals_step(pkg, ctx):
         assert nxt.tolist() == g["b4_ids"][step].tolist()
 
 
+def test_pipelined_decode_equals_step(pkg, ctx):
+    g, cfgd = load_golden()
+    cfg, m = _tiny_from_golden(pkg, ctx, cfgd, int(g["seed"]))
+    seqs = split_prompts(g, "b4")
+    m.step([0, 1, 2, 3], seqs, is_prefill=True)
+    got = []
+    m.decode_enqueue()
+    for _ in range(9):
+        m.decode_enqueue()          # one step ahead of the collected one
+        got.append(m.decode_collect()[:4].tolist())
+    got.append(m.decode_collect()[:4].tolist())
+    assert got == [g["b4_ids"][s].tolist() for s in range(1, 11)]
+    with pytest.raises(pkg._lib.NvllmError):
+        m.decode_collect()  # nothing enqueued
+
+
 def test_seq_free_returns_blocks_and_ids_can_restart(pkg, ctx):
     cfg = pkg.Qwen3Config.tiny()
     m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=3, ctx=ctx)
