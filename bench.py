@@ -10,8 +10,12 @@ enqueued ahead (nvllm_decode_enqueue / nvllm_decode_collect).
 
 N = 1  Qwen3-0.6B shapes, 64 live sequences (BASELINE.json configs[2] steady state: prompt lengths
        uniform 64..512, seed 0), synthetic bf16 weights generated in HBM, prefill untimed.
-N > 1  the same workload tensor-parallel over N ranks (one process per GPU, RCCL all-reduce after
-       o_proj and down_proj, vocab-parallel LM head): total work fixed => "strong" scaling.
+N > 1  sequences are independent units: every GPU serves its own 64 sequences with the TP=1 path, no
+       data-path collective => `value` = N x per-replica rate, "weak" scaling (--parallel tp serves ONE batch
+       tensor-parallel instead).
+Every run also carries `tp_scaling`: decode tokens/s of Qwen3-32B (configs[4]: batch 64, prompt 128) at TP = N
+over RCCL (row/column-parallel linears, 2 all-reduces per layer, vocab-parallel LM head), so the N = 1, 2, 4, 8
+lines together are the TP=1/2/4/8 scaling curve the north_star asks for.
 
 Prints ONE JSON line on rank 0 (driver contract) with `roofline` (dominant kernel, HIP events on the
 library stream) and `cpu_baseline` (the C oracle in the reference's no-KV-cache mode on host cores).
@@ -41,6 +45,15 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seqs", type=int, default=2, help="sequences of the batch the CPU baseline re-runs")
     ap.add_argument("--profile-steps", type=int, default=8, help="extra steps for the per-kernel HIP-event pass")
+    ap.add_argument("--parallel", default="dp", choices=["dp", "tp"],
+                    help="N>1: dp = one TP=1 replica per GPU (weak scaling, no collective); tp = one TP=N group")
+    ap.add_argument("--skip-tp-leg", action="store_true", help="do not run the tensor-parallel leg (tp_scaling)")
+    ap.add_argument("--tp-model", default="qwen3-32b", choices=["qwen3-0.6b", "qwen3-8b", "qwen3-32b", "tiny"])
+    ap.add_argument("--tp-batch", type=int, default=64)
+    ap.add_argument("--tp-prompt", type=int, default=128)
+    ap.add_argument("--tp-steps", type=int, default=32)
+    ap.add_argument("--tp-timeout", type=float, default=420.0)
+    ap.add_argument("--force-device", type=int, default=-1, help="testing aid: every rank uses this GPU ordinal")
     return ap.parse_args()
 
 
@@ -78,11 +91,58 @@ def cpu_baseline(cfg, prompts, n_seqs, seed):
                       f"reference mode: no KV cache, full re-forward, LM head on all rows; {dt:.1f} s"}
 
 
+def run_tp_extra(pkg, torch, dist, a, rank, world, local_rank):
+    """Tensor-parallel leg (north_star: column/row-parallel linears over RCCL, TP=1/2/4/8 scaling on Qwen3-32B):
+    decode tokens/s of `--tp-model` at TP = world on synthetic prompts, all ranks in one RCCL group."""
+    import numpy as np
+
+    rccl_id = None
+    if world > 1:
+        box = [pkg.Context.make_rccl_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        rccl_id = box[0]
+    ctx = pkg.Context(local_rank, tp_rank=rank, tp_size=world, rccl_id=rccl_id)
+    cfg = model_config(pkg, a.tp_model)
+    model = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=a.seed, ctx=ctx)
+    B, P, steps, warm = a.tp_batch, a.tp_prompt, a.tp_steps, 4
+    rng = np.random.default_rng(a.seed + 1)
+    prompts = [rng.integers(0, cfg.vocab_size, size=P, dtype=np.uint32).tolist() for _ in range(B)]
+    model.kv_alloc(num_blocks=B * (-(-(P + steps + warm + 4) // 256)) + 2, max_seqs=B, max_batched_tokens=4096)
+    model.step(list(range(B)), prompts, is_prefill=True)
+    for _ in range(warm):
+        model.decode_next()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    byts = 0
+    for _ in range(steps):
+        model.decode_next()
+        byts += model.last_step_bytes
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    res = {"model": a.tp_model, "tp": world, "batch": B, "prompt": P, "steps": steps, "tokens_per_s": B * steps / dt,
+           "ms_per_step": dt * 1e3 / steps, "per_rank_bytes_per_step": byts / steps,
+           "per_rank_hbm_frac": (byts / steps) / (dt / steps) / 1e9 / HBM_PEAK_GBS,
+           "collectives": "2 RCCL all-reduce(sum) of [batch, hidden] f32 per layer + (max,idx) all-gather" if world > 1 else "none"}
+    model.close()
+    ctx.close()
+    return res
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if a.force_device >= 0:
+        local_rank = a.force_device
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -92,21 +152,28 @@ def main():
     import nano_vllm_candle_amd as pkg
 
     dist = None
-    rccl_id = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane (id exchange, barrier, max over ranks) on gloo; the data path is RCCL inside the library
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    # Headline workload.  --parallel tp: the batch is served tensor-parallel over all ranks (one RCCL group).
+    # --parallel dp (default for N > 1): sequences are independent units, so every GPU serves its own 64
+    # sequences with the TP=1 path and no data-path collective ("weak" scaling); the TP leg below measures the
+    # collective path on the model it is meant for.
+    use_tp = a.parallel == "tp" and world > 1
+    rccl_id = None
+    if use_tp:
         box = [pkg.Context.make_rccl_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         rccl_id = box[0]
-    torch.cuda.set_device(local_rank)
-    ctx = pkg.Context(local_rank, tp_rank=rank, tp_size=world, rccl_id=rccl_id)
+    ctx = pkg.Context(local_rank, tp_rank=rank if use_tp else 0, tp_size=world if use_tp else 1, rccl_id=rccl_id)
+    tpw = world if use_tp else 1
     cfg = model_config(pkg, a.model)
     model = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=a.seed, ctx=ctx)
-    prompts = make_prompts(cfg, a.batch, a.prompt_min, a.prompt_max, a.seed)
+    prompts = make_prompts(cfg, a.batch, a.prompt_min, a.prompt_max, a.seed + (0 if use_tp else rank))
     total_steps = a.warmup + a.steps + a.profile_steps + 2
     max_len = max(len(p) for p in prompts) + total_steps
     blocks = sum(-(-(len(p) + total_steps) // 256) for p in prompts) + 2
@@ -153,7 +220,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt * 1e3 / a.steps
-    tok_s = a.batch * a.steps / dt
+    replicas = 1 if use_tp else world
+    tok_s = replicas * a.batch * a.steps / dt  # whole job: every replica serves its own batch
     mean_ctx = float(ctx_lens.mean()) - a.steps / 2
 
     # per-kernel HIP-event pass (outside the timed region; same process, same resident state)
@@ -173,7 +241,7 @@ def main():
     kv_layer = model.kv_bytes_per_token // cfg.num_hidden_layers  # K+V bytes of one token in one layer (this rank)
     # dominant kernel = the class that moves the most algorithmic bytes per step (the path is HBM-bound); the
     # HIP-event brackets add ~2 us per launch, so ranking by bracketed time would favour many-launch classes
-    lm_bytes = cfg.hidden_size * (cfg.vocab_size // world) * 2
+    lm_bytes = cfg.hidden_size * (cfg.vocab_size // tpw) * 2
     step_bytes_by_kind = {"attn": float(np.mean(attn_ctx)) * kv_layer * cfg.num_hidden_layers,
                           "gemm": float(model.weight_bytes - lm_bytes), "lm_head": float(lm_bytes)}
     dom = max(step_bytes_by_kind, key=step_bytes_by_kind.get)
@@ -183,10 +251,10 @@ def main():
         dom_bytes = float(np.mean(attn_ctx)) * kv_layer
         dom_name = "attn_paged_kernel<128, 1, 4, true>"
     elif dom == "lm_head":
-        dom_bytes = float(cfg.hidden_size * (cfg.vocab_size // world) * 2)
+        dom_bytes = float(lm_bytes)
         dom_name = "gemm_kernel (LM head)"
     elif dom == "gemm":
-        dom_bytes = float(model.weight_bytes - cfg.hidden_size * (cfg.vocab_size // world) * 2) / (4 * cfg.num_hidden_layers)
+        dom_bytes = float(model.weight_bytes - lm_bytes) / (4 * cfg.num_hidden_layers)
         dom_name = "gemm_kernel (layer projections, mean of qkv/o/gate_up/down)"
     else:
         dom_bytes = None
@@ -209,11 +277,12 @@ def main():
     out = {
         "metric": "decode tokens/sec", "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "scaling": "strong" if use_tp else "weak", "vs_baseline": None,
         "dtype": "bf16 weights, f16 KV cache, bf16x2(hi+lo)/f16 MFMA operands, f32 accumulate",
         "data": "synthetic",
         "config": {"workload": f"{a.model} decode, {a.batch} live sequences, prompts U[{a.prompt_min},{a.prompt_max}] seed {a.seed}",
-                   "batch": a.batch, "mean_context": round(mean_ctx, 1), "parallelism": f"tp{world}"},
+                   "batch": a.batch, "global_batch": a.batch * replicas, "mean_context": round(mean_ctx, 1),
+                   "parallelism": f"tp{world}" if use_tp else (f"dp{world} x tp1 (independent replicas, no collective)" if world > 1 else "tp1")},
         "roofline": roof,
         "step_roofline": {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": step_gbs / HBM_PEAK_GBS, "bytes_per_step": bytes_total / a.steps,
@@ -222,13 +291,40 @@ def main():
     }
     # prefill is the MFMA-bound side: algorithmic flops = 2 * matmul params * tokens (attention excluded);
     # the kernels issue 2x that on the MFMA pipe because activations are bf16 hi + lo
-    mm_params = (model.weight_bytes * world) / 2
+    mm_params = (model.weight_bytes * tpw) / 2
     pf_tflops = 2.0 * mm_params * prefill_tokens / prefill_s / 1e12
     out["prefill"] = {"tokens": prefill_tokens, "ms": prefill_s * 1e3, "tokens_per_s": prefill_tokens / prefill_s,
-                      "algorithmic_tflops": pf_tflops, "mfma_peak_tflops_bf16_dense": 2500.0 * world,
-                      "frac_of_mfma_peak": pf_tflops / (2500.0 * world), "note": "first call, includes one-time setup"}
+                      "algorithmic_tflops": pf_tflops, "mfma_peak_tflops_bf16_dense": 2500.0 * tpw,
+                      "frac_of_mfma_peak": pf_tflops / (2500.0 * tpw), "note": "first call, includes one-time setup"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:  # reported at N=1 only (driver contract)
         out["cpu_baseline"] = cpu_baseline(cfg, prompts, a.cpu_seqs, a.seed)
+    # ---- tensor-parallel leg: same process group, RCCL data path, its own model; guarded by a watchdog so that
+    # ---- a collective that never completes cannot swallow the headline line
+    if not a.skip_tp_leg:
+        model.close()
+        done = {"printed": False}
+
+        def bail():
+            if not done["printed"]:
+                done["printed"] = True
+                out["tp_scaling"] = {"model": a.tp_model, "tp": world, "error": f"timed out after {a.tp_timeout} s"}
+                if rank == 0:
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+        import threading
+
+        wd = threading.Timer(a.tp_timeout, bail)
+        wd.daemon = True
+        wd.start()
+        try:
+            out["tp_scaling"] = run_tp_extra(pkg, torch, dist, a, rank, world, local_rank)
+        except Exception as e:  # noqa: BLE001 -- report, never lose the headline number
+            out["tp_scaling"] = {"model": a.tp_model, "tp": world, "error": repr(e)[:300]}
+        wd.cancel()
+        if done["printed"]:
+            return
+        done["printed"] = True
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

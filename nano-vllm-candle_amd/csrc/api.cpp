@@ -686,7 +686,7 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     const size_t R = m->max_rows;
     const size_t wide = std::max<size_t>({(size_t)m->H, (size_t)m->nh_l * m->hd, (size_t)m->I_l});
     const size_t nmax = std::max<size_t>({(size_t)(m->nh_l + 2 * m->kv_l) * m->hd, (size_t)m->H, (size_t)2 * m->I_l});
-    m->slab_floats = std::max<size_t>(R * nmax, (size_t)8 * std::min<size_t>(R, 128) * nmax);
+    m->slab_floats = std::max<size_t>(R * nmax, (size_t)32 * std::min<size_t>(R, 128) * nmax);
     if (!rc) rc = dmalloc(ctx, &m->d_ids, R);
     if (!rc) rc = dmalloc(ctx, &m->d_pos, R);
     if (!rc) rc = dmalloc(ctx, &m->d_slot, R);
@@ -910,6 +910,25 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
     return NVLLM_OK;
 }
 
+// y (f32 slabs) = x.W^T on the generic path: for few rows the row-parallel streaming kernel (every load of a
+// workgroup issued up front) beats the chunked kernel on big matrices; otherwise the chunked kernel.
+static int gemm_slabs(nvllm_model* m, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w, float* out, int R,
+                      int max_split, int* n_slabs) {
+    nvllm_ctx* ctx = m->ctx;
+    if (R <= kFusedMaxRows && gemm_rowpar_ok(w.N, w.K, 2, R) &&
+        (size_t)gemm_rowpar_splits(w.N, w.K, 2, R) * R * w.N <= m->slab_floats && !getenv("NVLLM_NO_ROWPAR")) {
+        RowParArgs ra;
+        ra.xh = xh; ra.xl = xl; ra.ldx = ldx; ra.out = out; ra.M = R;
+        PROF(m, PROF_GEMM, launch_gemm_rowpar(ra, w, 2, ctx->stream));
+        *n_slabs = gemm_rowpar_splits(w.N, w.K, 2, R);
+        return NVLLM_OK;
+    }
+    GemmPlan p = plan_gemm(R, w.N, w.K, max_split);
+    PROF(m, PROF_GEMM, launch_gemm(p, xh, xl, ldx, w, out, R, ctx->stream));
+    *n_slabs = p.n_split;
+    return NVLLM_OK;
+}
+
 // rows R (ids/pos/slot/tiles already on the device), n_last rows listed in d_last_rows -> logits rows
 static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last, int logits_row0) {
     if (m->fused_ok && R <= kFusedMaxRows && !m->taps && !getenv("NVLLM_NO_FUSED"))
@@ -933,10 +952,10 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         }
         PROF(m, PROF_NORM, launch_add_rmsnorm(na, R, s));
         // QKV projection (qwen3.rs:205)
-        GemmPlan pq = plan_gemm(R, NQ, H, 8);
-        PROF(m, PROF_GEMM, launch_gemm(pq, m->xh, m->xl, H, w.qkv, m->slabs, R, s));
         QkvArgs qa;
-        qa.qkv = m->slabs; qa.n_slabs = pq.n_split; qa.slab_stride = (int64_t)R * NQ; qa.qn = w.qn; qa.kn = w.kn; qa.eps = eps;
+        int rcg = gemm_slabs(m, m->xh, m->xl, H, w.qkv, m->slabs, R, 8, &qa.n_slabs);
+        if (rcg) return rcg;
+        qa.qkv = m->slabs; qa.slab_stride = (int64_t)R * NQ; qa.qn = w.qn; qa.kn = w.kn; qa.eps = eps;
         qa.cos = m->cosv; qa.sin = m->sinv; qa.pos = m->d_pos; qa.slot = m->d_slot; qa.block_tables = m->d_block_tables;
         qa.max_blocks = m->max_blocks; qa.nh_l = m->nh_l;
         qa.q_scale = powf((float)hd, -0.5f) * 1.4426950408889634f;  // head_dim^-0.5 (qwen3.rs:134) * log2(e)
@@ -961,22 +980,39 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
         // output projection (qwen3.rs:278) + TP all-reduce
         const int KO = m->nh_l * hd;
-        GemmPlan po = plan_gemm(R, H, KO, 8);
-        PROF(m, PROF_GEMM, launch_gemm(po, m->xh, m->xl, KO, w.o, m->slabs, R, s));
+        int o_slabs = 1;
+        rcg = gemm_slabs(m, m->xh, m->xl, KO, w.o, m->slabs, R, 8, &o_slabs);
+        if (rcg) return rcg;
         const float* oin; int ons;
-        int rc = tp_reduce(m, R, po.n_split, &oin, &ons);
+        int rc = tp_reduce(m, R, o_slabs, &oin, &ons);
         if (rc) return rc;
         NormArgs nb;  // post-attention add + norm (qwen3.rs:393)
         nb.in = oin; nb.n_slabs = ons; nb.slab_stride = (int64_t)R * H; nb.residual_in = m->resid; nb.residual_out = m->resid;
         nb.weight = w.ln2; nb.eps = eps; nb.H = H; nb.xh = m->xh; nb.xl = m->xl;
         PROF(m, PROF_NORM, launch_add_rmsnorm(nb, R, s));
         // MLP (qwen3.rs:323-327)
-        // gate/up GEMM with the SiLU*mul epilogue: act hi/lo written directly, no slabs, no extra launch
-        GemmPlan pg = plan_gemm_swiglu(R, 2 * m->I_l, H);
-        PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, s));
-        GemmPlan pd = plan_gemm(R, H, m->I_l, 8);
-        PROF(m, PROF_GEMM, launch_gemm(pd, m->xh2, m->xl2, m->I_l, w.down, m->slabs, R, s));
-        rc = tp_reduce(m, R, pd.n_split, &prev, &prev_ns);
+        if (R <= kFusedMaxRows && gemm_rowpar_ok(2 * m->I_l, H, 1, R)) {
+            // small gate/up: whole-K row-parallel kernel with the SiLU*mul epilogue
+            RowParArgs rg;
+            rg.xh = m->xh; rg.xl = m->xl; rg.ldx = H; rg.oh = m->xh2; rg.ol = m->xl2; rg.M = R;
+            PROF(m, PROF_GEMM, launch_gemm_rowpar(rg, w.gu, 1, s));
+        } else if (R <= kFusedMaxRows && gemm_rowpar_ok(2 * m->I_l, H, 2, R) &&
+                   (size_t)gemm_rowpar_splits(2 * m->I_l, H, 2, R) * R * 2 * m->I_l <= m->slab_floats && !getenv("NVLLM_NO_ROWPAR")) {
+            // big gate/up at few rows: stream it with K slices (f32 slabs of the INTERLEAVED gate/up rows),
+            // then SiLU*mul on the summed slabs
+            int gs = 1;
+            rcg = gemm_slabs(m, m->xh, m->xl, H, w.gu, m->slabs, R, 8, &gs);
+            if (rcg) return rcg;
+            PROF(m, PROF_SILU, launch_silu_mul_interleaved(m->slabs, gs, (int64_t)R * 2 * m->I_l, R, m->I_l, m->xh2, m->xl2, s));
+        } else {
+            // gate/up GEMM with the SiLU*mul epilogue: act hi/lo written directly, no slabs, no extra launch
+            GemmPlan pg = plan_gemm_swiglu(R, 2 * m->I_l, H);
+            PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, s));
+        }
+        int d_slabs = 1;
+        rcg = gemm_slabs(m, m->xh2, m->xl2, m->I_l, w.down, m->slabs, R, 8, &d_slabs);
+        if (rcg) return rcg;
+        rc = tp_reduce(m, R, d_slabs, &prev, &prev_ns);
         if (rc) return rc;
         if (m->taps) {
             HIPCHK(ctx, launch_slab_sum(prev, prev_ns, (int64_t)R * H, nullptr, R, H, m->tap_h + (size_t)l * m->max_rows * H, s));
@@ -1687,6 +1723,7 @@ extern "C" int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int 
     hipStream_t s = ctx->stream;
     GemmPlan p = mode == 2 ? plan_gemm_swiglu(M, N, K) : plan_gemm(M, N, K, 64);
     if (mt > 0) { p.mt = mt; p.kc = mt == 8 ? 2 : 4; }
+    if (getenv("NVLLM_GEMM_KC")) p.kc = atoi(getenv("NVLLM_GEMM_KC"));
     if (nt > 0) p.nt = nt;
     if (nw > 0) p.nw = nw;
     set_split(p, K / 32, n_split > 0 ? n_split : p.n_split);

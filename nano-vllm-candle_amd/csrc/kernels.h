@@ -187,6 +187,7 @@ struct RowParArgs {
 };
 bool gemm_rowpar_supported(int N, int K);
 bool gemm_rowpar_ok(int N, int K, int epi, int M);
+int gemm_rowpar_splits(int N, int K, int epi, int M);  // f32 slabs the plain epilogue leaves (1 = complete sums)
 int gemm_rowpar_groups(int N, int K);
 // epi: 0 residual + next-norm prep, 1 SwiGLU, 2 plain f32 output
 hipError_t launch_gemm_rowpar(const RowParArgs& a, const PackedW& w, int epi, hipStream_t s);
@@ -195,6 +196,10 @@ hipError_t launch_gemm_rowpar(const RowParArgs& a, const PackedW& w, int epi, hi
 // gu [n_slabs][rows][2*I] -> act hi/lo [rows][I] (and/or f32 y)
 hipError_t launch_silu_mul(const float* gu, int n_slabs, int64_t slab_stride, int rows, int I, bf16_bits* hi,
                            bf16_bits* lo, float* y, hipStream_t s);
+
+// gu in the packed weight's interleaved 16-row-tile order (gate tile, up tile, ...) -> act hi/lo [rows][I]
+hipError_t launch_silu_mul_interleaved(const float* gu, int n_slabs, int64_t slab_stride, int rows, int I, bf16_bits* hi,
+                                       bf16_bits* lo, hipStream_t s);
 
 // ---- misc --------------------------------------------------------------------------------------------
 // y[r][:] = sum_s in[s][r][:] (+ bias)  -- finishes a split-K GEMM for the fine-seam op

@@ -534,6 +534,8 @@ static hipError_t gemm_dispatch_nw(const GemmPlan& p, const bf16_bits* xh, const
     NVLLM_GEMM_CASE(4, 2, 4)
     NVLLM_GEMM_CASE(8, 2, 2)
     if constexpr (NW == 4) { NVLLM_GEMM_CASE(8, 4, 2) }  // prefill tile: 128 rows x 256 features per workgroup
+    if constexpr (NW == 8 && MODE != 2) { NVLLM_GEMM_CASE(4, 1, 8) }  // big-K streaming: 256-deep chunks
+    if constexpr (NW == 8) { NVLLM_GEMM_CASE(4, 2, 8) }
 #undef NVLLM_GEMM_CASE
     return hipErrorInvalidValue;
 }
@@ -616,22 +618,26 @@ hipError_t launch_argmax_parts(const float* part_val, const int* part_idx, int n
 // image comes from L2 while the weights are already in registers).  Partial sums meet in LDS, the k-slice-0
 // waves run the epilogue.  Rows are split over blockIdx.z (weights re-read through L2 by the row blocks).
 // ---------------------------------------------------------------------------------------------------
-template <int NWN, int NWK, int TPW, int PH, int EPI>
+template <int MT, int NWN, int NWK, int TPW, int PH, int EPI>
 __global__ void __launch_bounds__(NWN * NWK * 64) gemm_rowpar_kernel(RowParArgs a, const uint4* __restrict__ wp, int N, int KT) {
     constexpr int NW = NWN * NWK;
-    constexpr int KTP = NWK * TPW;            // k-tiles per phase (<= 32: one x image <= 64 KiB)
+    constexpr int KTP = NWK * TPW;            // k-tiles per phase (MT*KTP <= 32: one x image <= 64 KiB)
     constexpr int NBUF = PH > 1 ? 2 : 1;      // x images resident at once
+    constexpr int IMG = 2 * MT * KTP;         // 1 KiB fragments per x image: [2 planes][MT][KTP]
+    constexpr int NR = 16 * MT;               // rows per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    uint4* lds_x = reinterpret_cast<uint4*>(smem_raw);                                  // [NBUF][2 planes][KTP][64]
+    uint4* lds_x = reinterpret_cast<uint4*>(smem_raw);                                  // [NBUF][IMG][64]
     // the cross-wave reduction buffer aliases the x image (dead after the last compute; one extra barrier)
-    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                                    // [NW][64]
-    float* sred = reinterpret_cast<float*>(smem_raw + (size_t)NBUF * 2 * KTP * 1024);   // [NWN][16] / rinv partials [4][16]
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                                    // [NW][MT][64]
+    constexpr size_t kMainBytes = (size_t)NBUF * IMG * 1024 > (size_t)NW * MT * 1024 ? (size_t)NBUF * IMG * 1024 : (size_t)NW * MT * 1024;
+    float* sred = reinterpret_cast<float*>(smem_raw + kMainBytes);                      // [NWN][NR] / rinv partials [4][NR]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, grp = lane >> 4;
     const int wn = wave / NWK, wk = wave % NWK;
     const int ntiles = N >> 4;
     const int ntile = min((int)blockIdx.x * NWN + wn, ntiles - 1);
-    const int m0 = blockIdx.z * 16;
+    const int m0 = blockIdx.z * NR;
+    const int kb = blockIdx.y * (PH * KTP);   // first k-tile of this workgroup's K slice (split-K over blockIdx.y)
     const int M = a.M;
 
     // every weight fragment of this wave, all phases, issued before anything else (HBM -> VGPR)
@@ -639,45 +645,59 @@ __global__ void __launch_bounds__(NWN * NWK * 64) gemm_rowpar_kernel(RowParArgs 
 #pragma unroll
     for (int p = 0; p < PH; ++p)
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) w[p][t] = wp[((size_t)ntile * KT + p * KTP + wk * TPW + t) * 64 + lane];
+        for (int t = 0; t < TPW; ++t) w[p][t] = wp[((size_t)ntile * KT + kb + p * KTP + wk * TPW + t) * 64 + lane];
 
-    const int xrow = min(m0 + l15, M - 1);
+    int xrows[MT];
+#pragma unroll
+    for (int b = 0; b < MT; ++b) xrows[b] = min(m0 + b * 16 + l15, M - 1);
     auto stage = [&](int p, int buf) {
 #pragma unroll
-        for (int i = 0; i < (2 * KTP) / NW; ++i) {
+        for (int i = 0; i < IMG / NW; ++i) {
             const int f = wave + i * NW;
-            const int plane = f / KTP, k = f - plane * KTP;
-            const uint16_t* src = (plane ? a.xl : a.xh) + (size_t)xrow * a.ldx + (size_t)(p * KTP + k) * 32 + grp * 8;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_x + (size_t)(buf * 2 * KTP + f) * 64), 16, 0, 0);
+            const int plane = f / (MT * KTP);
+            const int rem = f - plane * (MT * KTP);
+            const int mt = rem / KTP, k = rem - mt * KTP;
+            const uint16_t* src = (plane ? a.xl : a.xh) + (size_t)xrows[mt] * a.ldx + (size_t)(kb + p * KTP + k) * 32 + grp * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_x + (size_t)(buf * IMG + f) * 64), 16, 0, 0);
         }
     };
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MT];
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](const uint4 (&wf)[TPW], int buf) {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
             const int kl = wk * TPW + t;
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, lds_x[(size_t)(buf * 2 * KTP + kl) * 64 + lane]);
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, lds_x[(size_t)(buf * 2 * KTP + KTP + kl) * 64 + lane]);
             const bf16x8 wv = __builtin_bit_cast(bf16x8, wf[t]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, bl, acc, 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, lds_x[(size_t)(buf * IMG + (0 * MT + b) * KTP + kl) * 64 + lane]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, lds_x[(size_t)(buf * IMG + (1 * MT + b) * KTP + kl) * 64 + lane]);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, bh, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, bl, acc[b], 0, 0, 0);
+            }
         }
     };
-    // x images: the first two phases are in flight together with the weights (one memory round trip for
-    // K <= 2048); later phases are staged into the buffer that was just consumed
+    // x images: the first two phases are in flight together with the weights (one memory round trip for short K);
+    // later phases are staged into the buffer that was just consumed
     stage(0, 0);
     if constexpr (PH > 1) stage(1, 1);
     // epilogue operands are independent of the product: fetch them now, behind the streaming loads
-    const int row = m0 + l15;
-    const bool valid = (wk == 0) && row < M && ((int)blockIdx.x * NWN + wn) < ntiles;
-    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f), nw4 = r4;
+    const bool tile_ok = ((int)blockIdx.x * NWN + wn) < ntiles;
+    float4 r4[MT], nw4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int b = 0; b < MT; ++b) r4[b] = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (EPI == 0) {
-        if (valid) {
-            r4 = *reinterpret_cast<const float4*>(a.resid_in + (size_t)row * N + (size_t)ntile * 16 + grp * 4);
+        if (wk == 0 && tile_ok) {
             nw4 = *reinterpret_cast<const float4*>(a.next_w + (size_t)ntile * 16 + grp * 4);
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const int row = m0 + b * 16 + l15;
+                if (row < M) r4[b] = *reinterpret_cast<const float4*>(a.resid_in + (size_t)row * N + (size_t)ntile * 16 + grp * 4);
+            }
         }
     }
-    if constexpr (EPI == 1) rownorm_partials<16>(a.rn, m0, M, sred);
+    if constexpr (EPI == 1) rownorm_partials<NR>(a.rn, m0, M, sred);
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < PH; ++p) {
@@ -686,86 +706,130 @@ __global__ void __launch_bounds__(NWN * NWK * 64) gemm_rowpar_kernel(RowParArgs 
             __syncthreads();  // WAR: all waves are done with buffer p&1
             stage(p + 2, p & 1);
         }
-        if (p + 1 < PH && p + 2 < PH + 1 && p >= 1) __syncthreads();  // phase p+1 (staged after the first barrier) landed
+        if (p + 1 < PH && p >= 1) __syncthreads();  // phase p+1 (staged after the first barrier) landed
     }
     __syncthreads();  // every wave is done reading the x image: it becomes the reduction buffer
-    red[(size_t)wave * 64 + lane] = acc;
+#pragma unroll
+    for (int b = 0; b < MT; ++b) red[(size_t)(wave * MT + b) * 64 + lane] = acc[b];
     __syncthreads();
     if (wk == 0) {
 #pragma unroll
-        for (int k = 1; k < NWK; ++k) {
-            const f32x4 v = red[(size_t)(wn * NWK + k) * 64 + lane];
-            acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
-        }
+        for (int k = 1; k < NWK; ++k)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const f32x4 v = red[(size_t)((wn * NWK + k) * MT + b) * 64 + lane];
+                acc[b][0] += v[0]; acc[b][1] += v[1]; acc[b][2] += v[2]; acc[b][3] += v[3];
+            }
     }
     if constexpr (EPI == 0) {
-        float ssq_part = 0.f;
         if (wk == 0) {
-            if (valid) {
-                const size_t o = (size_t)row * N + (size_t)ntile * 16 + grp * 4;
-                const float s0 = acc[0] + r4.x, s1 = acc[1] + r4.y, s2 = acc[2] + r4.z, s3 = acc[3] + r4.w;
-                *reinterpret_cast<float4*>(a.resid_out + o) = make_float4(s0, s1, s2, s3);
-                uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
-                split_bf16(s0 * nw4.x, h0, l0); split_bf16(s1 * nw4.y, h1, l1); split_bf16(s2 * nw4.z, h2, l2); split_bf16(s3 * nw4.w, h3, l3);
-                *reinterpret_cast<uint2*>(a.oh + o) = make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
-                *reinterpret_cast<uint2*>(a.ol + o) = make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
-                ssq_part = s0 * s0 + s1 * s1 + s2 * s2 + s3 * s3;
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const int row = m0 + b * 16 + l15;
+                float ssq_part = 0.f;
+                if (tile_ok && row < M) {
+                    const size_t o = (size_t)row * N + (size_t)ntile * 16 + grp * 4;
+                    const float s0 = acc[b][0] + r4[b].x, s1 = acc[b][1] + r4[b].y, s2 = acc[b][2] + r4[b].z, s3 = acc[b][3] + r4[b].w;
+                    *reinterpret_cast<float4*>(a.resid_out + o) = make_float4(s0, s1, s2, s3);
+                    uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
+                    split_bf16(s0 * nw4.x, h0, l0); split_bf16(s1 * nw4.y, h1, l1); split_bf16(s2 * nw4.z, h2, l2); split_bf16(s3 * nw4.w, h3, l3);
+                    *reinterpret_cast<uint2*>(a.oh + o) = make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
+                    *reinterpret_cast<uint2*>(a.ol + o) = make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
+                    ssq_part = s0 * s0 + s1 * s1 + s2 * s2 + s3 * s3;
+                }
+                ssq_part += __shfl_xor(ssq_part, 16);
+                ssq_part += __shfl_xor(ssq_part, 32);
+                if (grp == 0) sred[wn * NR + b * 16 + l15] = ssq_part;
             }
-            ssq_part += __shfl_xor(ssq_part, 16);
-            ssq_part += __shfl_xor(ssq_part, 32);
-            if (grp == 0) sred[wn * 16 + l15] = ssq_part;
         }
         __syncthreads();
-        if (wave == 0 && grp == 0 && row < M) {
-            float t = 0.f;
+        if (wave == 0) {
 #pragma unroll
-            for (int k = 0; k < NWN; ++k) t += sred[k * 16 + l15];
-            a.ssq[(size_t)blockIdx.x * a.ssq_stride + row] = t;
+            for (int b = 0; b < MT; ++b) {
+                const int row = m0 + b * 16 + l15;
+                if (grp == 0 && row < M) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NWN; ++k) t += sred[k * NR + b * 16 + l15];
+                    a.ssq[(size_t)blockIdx.x * a.ssq_stride + row] = t;
+                }
+            }
         }
     } else if constexpr (EPI == 1) {
-        // SwiGLU: n-tile 0 of the workgroup = gate, n-tile 1 = up of the same 16 features (interleaved weight)
+        // SwiGLU: even n-tile of a pair = gate, odd = up of the same 16 features (interleaved weight)
         static_assert(EPI != 1 || (NWN % 2 == 0), "SwiGLU epilogue pairs two n-tiles");
-        // odd n-tile waves (up) park their sums in their own slot; the even (gate) wave of the pair finishes
-        if (wk == 0 && (wn & 1)) red[(size_t)(wn * NWK) * 64 + lane] = acc;
+        // odd n-tile waves (up) park their sums in their own slots; the even (gate) wave of the pair finishes
+        if (wk == 0 && (wn & 1)) {
+#pragma unroll
+            for (int b = 0; b < MT; ++b) red[(size_t)((wn * NWK) * MT + b) * 64 + lane] = acc[b];
+        }
         __syncthreads();
         const int pair = (int)blockIdx.x * (NWN / 2) + (wn >> 1);  // activation feature tile
-        if (wk == 0 && !(wn & 1) && row < M && (pair * 2 + 1) < ntiles) {
-            const f32x4 up = red[(size_t)((wn + 1) * NWK) * 64 + lane];
-            const float ri = rownorm_rinv_lds<16>(a.rn, sred, l15);
+        if (wk == 0 && !(wn & 1) && (pair * 2 + 1) < ntiles) {
             const int I = N >> 1;
-            uint16_t h[4], l[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float g = acc[r] * ri, u = up[r] * ri;
-                split_bf16((g / (1.0f + __expf(-g))) * u, h[r], l[r]);
+            for (int b = 0; b < MT; ++b) {
+                const int row = m0 + b * 16 + l15;
+                if (row >= M) continue;
+                const f32x4 up = red[(size_t)(((wn + 1) * NWK) * MT + b) * 64 + lane];
+                const float ri = rownorm_rinv_lds<NR>(a.rn, sred, b * 16 + l15);
+                uint16_t h[4], l[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float g = acc[b][r] * ri, u = up[r] * ri;
+                    split_bf16((g / (1.0f + __expf(-g))) * u, h[r], l[r]);
+                }
+                const size_t o = (size_t)row * I + (size_t)pair * 16 + grp * 4;
+                *reinterpret_cast<uint2*>(a.oh + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+                *reinterpret_cast<uint2*>(a.ol + o) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
             }
-            const size_t o = (size_t)row * I + (size_t)pair * 16 + grp * 4;
-            *reinterpret_cast<uint2*>(a.oh + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
-            *reinterpret_cast<uint2*>(a.ol + o) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
         }
     } else {
-        if (wk == 0 && row < M && ((int)blockIdx.x * NWN + wn) < ntiles)
-            *reinterpret_cast<float4*>(a.out + (size_t)row * N + (size_t)ntile * 16 + grp * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (wk == 0 && tile_ok) {
+            float* o = a.out + (size_t)blockIdx.y * (size_t)M * N;  // split-K partial slab
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const int row = m0 + b * 16 + l15;
+                if (row < M)
+                    *reinterpret_cast<float4*>(o + (size_t)row * N + (size_t)ntile * 16 + grp * 4) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+            }
+        }
     }
 }
 
-struct RowParShape { int nwn, nwk, tpw, ph; };
+struct RowParShape { int mt, nwn, nwk, tpw, ph, ns; };
+// Decomposition of y[M,N] = x.W^T for the row-parallel kernel (false: use the generic kernel).
+//   small matrices: 16 rows per workgroup (row blocks re-read the weights through L2), whole K in one workgroup;
+//   big matrices (>= 24 MB): all rows (up to 64) in one workgroup so every weight byte crosses L2 once, K sliced
+//   into <= 1024-deep pieces over blockIdx.y (plain epilogue only: the slices leave f32 slabs).
 static bool rowpar_shape(int N, int K, int epi, int M, RowParShape& sh) {
     if (N % 16 || K % 32) return false;
-    const int KT = K / 32, ntiles = N / 16, mblocks = (std::max(M, 1) + 15) / 16;
-    // fewest phases whose x image fits 64 KiB (KTP <= 32 k-tiles), most k-slices per workgroup first
+    const int KT = K / 32, ntiles = N / 16;
+    const bool big = (size_t)N * K * 2 >= (size_t)24 << 20 && M > 16;
     static const int tpws[] = {8, 12, 16};
+    if (big) {
+        if (epi != 2) return false;
+        const int mt = 4;  // 64 rows: x image 2*4*8 KiB per phase
+        for (int ph = 4; ph >= 1; --ph) {
+            if (KT % (ph * 8)) continue;
+            sh = {mt, (ntiles % 8 == 0) ? 8 : (ntiles % 4 == 0 ? 4 : (ntiles % 2 == 0 ? 2 : 1)), 1, 8, ph, KT / (ph * 8)};
+            if ((2 * mt * 8) % sh.nwn) continue;
+            return true;
+        }
+        return false;
+    }
+    const int mblocks = (std::max(M, 1) + 15) / 16;
+    // fewest phases whose x image fits 64 KiB (KTP <= 32 k-tiles), most k-slices per workgroup first
     for (int ph = 1; ph <= 4; ++ph)
         for (int nwk : {4, 2, 1})
             for (int tpw : tpws) {
                 if (ph * nwk * tpw != KT || nwk * tpw > 32) continue;
                 int nwn = ntiles % 2 == 0 ? 2 : 1;
                 // wide projections (QKV, gate/up): 4 n-tiles per workgroup halves the x re-staging and keeps the
-                // whole grid resident in one round (2 workgroups of 16 waves per CU) -- only where it still
-                // leaves >= 192 workgroups
+                // whole grid resident in one round -- only where it still leaves >= 192 workgroups
                 if (epi != 0 && ph == 1 && nwk == 4 && tpw == 8 && ntiles % 4 == 0 && (ntiles / 4) * mblocks >= 192) nwn = 4;
                 if ((2 * tpw) % nwn) continue;
-                sh = {nwn, nwk, tpw, ph};
+                sh = {1, nwn, nwk, tpw, ph, 1};
                 return true;
             }
     return false;
@@ -776,32 +840,37 @@ bool gemm_rowpar_ok(int N, int K, int epi, int M) {
     return rowpar_shape(N, K, epi, M, sh) && !(epi == 1 && sh.nwn % 2);
 }
 int gemm_rowpar_groups(int N, int K) { RowParShape sh; if (!rowpar_shape(N, K, 0, 64, sh)) return 0; return (N / 16 + sh.nwn - 1) / sh.nwn; }
+int gemm_rowpar_splits(int N, int K, int epi, int M) { RowParShape sh; return rowpar_shape(N, K, epi, M, sh) ? sh.ns : 0; }
 
-template <int NWN, int NWK, int TPW, int PH, int EPI>
-static hipError_t rowpar_launch_t(const RowParArgs& a, const PackedW& w, hipStream_t s) {
-    constexpr int NW = NWN * NWK, KTP = NWK * TPW, NBUF = PH > 1 ? 2 : 1;
-    const size_t lds = std::max((size_t)NBUF * 2 * KTP * 1024, (size_t)NW * 1024) + 4 * 16 * 4;
+template <int MT, int NWN, int NWK, int TPW, int PH, int EPI>
+static hipError_t rowpar_launch_t(const RowParShape& sh, const RowParArgs& a, const PackedW& w, hipStream_t s) {
+    constexpr int NW = NWN * NWK, KTP = NWK * TPW, NBUF = PH > 1 ? 2 : 1, IMG = 2 * MT * KTP;
+    const size_t lds = std::max((size_t)NBUF * IMG * 1024, (size_t)NW * MT * 1024) + (size_t)4 * 16 * MT * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowpar_kernel<NWN, NWK, TPW, PH, EPI>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowpar_kernel<MT, NWN, NWK, TPW, PH, EPI>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dim3 grid((w.N / 16 + NWN - 1) / NWN, 1, (a.M + 15) / 16);
-    gemm_rowpar_kernel<NWN, NWK, TPW, PH, EPI><<<grid, NW * 64, lds, s>>>(a, w.data, w.N, w.K / 32);
+    dim3 grid((w.N / 16 + NWN - 1) / NWN, sh.ns, (a.M + 16 * MT - 1) / (16 * MT));
+    gemm_rowpar_kernel<MT, NWN, NWK, TPW, PH, EPI><<<grid, NW * 64, lds, s>>>(a, w.data, w.N, w.K / 32);
     return hipGetLastError();
 }
 
 template <int EPI>
 static hipError_t rowpar_dispatch(const RowParShape& sh, const RowParArgs& a, const PackedW& w, hipStream_t s) {
-#define NVLLM_RP(NWN_, NWK_, TPW_, PH_) \
-    if (sh.nwn == NWN_ && sh.nwk == NWK_ && sh.tpw == TPW_ && sh.ph == PH_) return rowpar_launch_t<NWN_, NWK_, TPW_, PH_, EPI>(a, w, s);
+#define NVLLM_RP(MT_, NWN_, NWK_, TPW_, PH_) \
+    if (sh.mt == MT_ && sh.nwn == NWN_ && sh.nwk == NWK_ && sh.tpw == TPW_ && sh.ph == PH_) return rowpar_launch_t<MT_, NWN_, NWK_, TPW_, PH_, EPI>(sh, a, w, s);
 #define NVLLM_RP_PH(NWN_, PH_)                                                                        \
-    NVLLM_RP(NWN_, 4, 8, PH_) NVLLM_RP(NWN_, 2, 8, PH_) NVLLM_RP(NWN_, 2, 12, PH_) NVLLM_RP(NWN_, 2, 16, PH_) \
-    NVLLM_RP(NWN_, 1, 8, PH_) NVLLM_RP(NWN_, 1, 12, PH_) NVLLM_RP(NWN_, 1, 16, PH_)
+    NVLLM_RP(1, NWN_, 4, 8, PH_) NVLLM_RP(1, NWN_, 2, 8, PH_) NVLLM_RP(1, NWN_, 2, 12, PH_) NVLLM_RP(1, NWN_, 2, 16, PH_) \
+    NVLLM_RP(1, NWN_, 1, 8, PH_) NVLLM_RP(1, NWN_, 1, 12, PH_) NVLLM_RP(1, NWN_, 1, 16, PH_)
     NVLLM_RP_PH(2, 1) NVLLM_RP_PH(2, 2) NVLLM_RP_PH(2, 3) NVLLM_RP_PH(2, 4)
     if constexpr (EPI != 1) { NVLLM_RP_PH(1, 1) NVLLM_RP_PH(1, 2) NVLLM_RP_PH(1, 3) NVLLM_RP_PH(1, 4) }
-    if constexpr (EPI != 0) { NVLLM_RP(4, 4, 8, 1) }
+    if constexpr (EPI != 0) { NVLLM_RP(1, 4, 4, 8, 1) }
+    if constexpr (EPI == 2) {  // big matrices: 64 rows per workgroup, K slices over blockIdx.y
+        NVLLM_RP(4, 8, 1, 8, 1) NVLLM_RP(4, 8, 1, 8, 2) NVLLM_RP(4, 8, 1, 8, 3) NVLLM_RP(4, 8, 1, 8, 4)
+        NVLLM_RP(4, 4, 1, 8, 1) NVLLM_RP(4, 4, 1, 8, 2) NVLLM_RP(4, 4, 1, 8, 3) NVLLM_RP(4, 4, 1, 8, 4)
+    }
 #undef NVLLM_RP_PH
 #undef NVLLM_RP
     return hipErrorNotSupported;
@@ -1470,6 +1539,39 @@ __global__ void __launch_bounds__(256) silu_mul_kernel(const float* __restrict__
         }
     }
 }
+// same for the INTERLEAVED gate/up layout of the packed weight (16-row tiles: gate tile, up tile, gate tile, ...)
+__global__ void __launch_bounds__(256) silu_mul_interleaved_kernel(const float* __restrict__ gu, int n_slabs,
+                                                                  int64_t slab_stride, int rows, int I,
+                                                                  uint16_t* __restrict__ hi, uint16_t* __restrict__ lo) {
+    const int64_t total = (int64_t)rows * (I >> 2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / (I >> 2));
+        const int c = (int)(i % (I >> 2)) * 4;  // activation feature (4 consecutive, inside one 16-tile)
+        const float* pg = gu + (size_t)r * 2 * I + (size_t)(c >> 4) * 32 + (c & 15);
+        float4 g = *reinterpret_cast<const float4*>(pg);
+        float4 u = *reinterpret_cast<const float4*>(pg + 16);
+        for (int sl = 1; sl < n_slabs; ++sl) {
+            const float4 g2 = *reinterpret_cast<const float4*>(pg + (size_t)sl * slab_stride);
+            const float4 u2 = *reinterpret_cast<const float4*>(pg + (size_t)sl * slab_stride + 16);
+            g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+            u.x += u2.x; u.y += u2.y; u.z += u2.z; u.w += u2.w;
+        }
+        const float y0 = (g.x / (1.0f + __expf(-g.x))) * u.x, y1 = (g.y / (1.0f + __expf(-g.y))) * u.y;
+        const float y2 = (g.z / (1.0f + __expf(-g.z))) * u.z, y3 = (g.w / (1.0f + __expf(-g.w))) * u.w;
+        uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
+        split_bf16(y0, h0, l0); split_bf16(y1, h1, l1); split_bf16(y2, h2, l2); split_bf16(y3, h3, l3);
+        *reinterpret_cast<uint2*>(hi + (size_t)r * I + c) = make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
+        *reinterpret_cast<uint2*>(lo + (size_t)r * I + c) = make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
+    }
+}
+hipError_t launch_silu_mul_interleaved(const float* gu, int n_slabs, int64_t slab_stride, int rows, int I, bf16_bits* hi,
+                                       bf16_bits* lo, hipStream_t s) {
+    if (I % 16 != 0) return hipErrorInvalidValue;
+    if (rows <= 0) return hipSuccess;
+    silu_mul_interleaved_kernel<<<grid_for((int64_t)rows * (I / 4)), 256, 0, s>>>(gu, n_slabs, slab_stride, rows, I, hi, lo);
+    return hipGetLastError();
+}
+
 hipError_t launch_silu_mul(const float* gu, int n_slabs, int64_t slab_stride, int rows, int I, bf16_bits* hi,
                            bf16_bits* lo, float* y, hipStream_t s) {
     if (I % 4 != 0) return hipErrorInvalidValue;
