@@ -52,8 +52,9 @@ def parse():
     ap.add_argument("--tp-batch", type=int, default=64)
     ap.add_argument("--tp-prompt", type=int, default=128)
     ap.add_argument("--tp-steps", type=int, default=32)
-    ap.add_argument("--tp-timeout", type=float, default=420.0)
+    ap.add_argument("--tp-timeout", type=float, default=300.0)
     ap.add_argument("--force-device", type=int, default=-1, help="testing aid: every rank uses this GPU ordinal")
+    ap.add_argument("--tp-leg-child", action="store_true", help=argparse.SUPPRESS)  # internal: run only the TP leg
     return ap.parse_args()
 
 
@@ -159,6 +160,15 @@ def main():
         # control plane (id exchange, barrier, max over ranks) on gloo; the data path is RCCL inside the library
         dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
+    if a.tp_leg_child:
+        # child process of a bench rank: only the tensor-parallel leg, result as one JSON line on stdout (rank 0)
+        res = run_tp_extra(pkg, torch, dist, a, rank, world, local_rank)
+        if rank == 0:
+            print("TP_LEG_RESULT " + json.dumps(res), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # Headline workload.  --parallel tp: the batch is served tensor-parallel over all ranks (one RCCL group).
     # --parallel dp (default for N > 1): sequences are independent units, so every GPU serves its own 64
     # sequences with the TP=1 path and no data-path collective ("weak" scaling); the TP leg below measures the
@@ -298,33 +308,36 @@ def main():
                       "frac_of_mfma_peak": pf_tflops / (2500.0 * tpw), "note": "first call, includes one-time setup"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:  # reported at N=1 only (driver contract)
         out["cpu_baseline"] = cpu_baseline(cfg, prompts, a.cpu_seqs, a.seed)
-    # ---- tensor-parallel leg: same process group, RCCL data path, its own model; guarded by a watchdog so that
-    # ---- a collective that never completes cannot swallow the headline line
+    # ---- tensor-parallel leg, in a CHILD process per rank (own rendezvous port): an RCCL crash or a collective that
+    # ---- never completes costs the tp_scaling entry, never the headline line
     if not a.skip_tp_leg:
+        import subprocess
+
         model.close()
-        done = {"printed": False}
-
-        def bail():
-            if not done["printed"]:
-                done["printed"] = True
-                out["tp_scaling"] = {"model": a.tp_model, "tp": world, "error": f"timed out after {a.tp_timeout} s"}
-                if rank == 0:
-                    print(json.dumps(out), flush=True)
-                os._exit(0)
-
-        import threading
-
-        wd = threading.Timer(a.tp_timeout, bail)
-        wd.daemon = True
-        wd.start()
+        env = dict(os.environ)
+        env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
+        env["MASTER_ADDR"] = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        # torchrun makes its ranks clients of the launcher's store; on the new port child rank 0 must host its own
+        env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+        cmd = [sys.executable, os.path.abspath(__file__), "--tp-leg-child", "--gpus", str(world), "--tp-model", a.tp_model,
+               "--tp-batch", str(a.tp_batch), "--tp-prompt", str(a.tp_prompt), "--tp-steps", str(a.tp_steps),
+               "--seed", str(a.seed)]
+        if a.force_device >= 0:
+            cmd += ["--force-device", str(a.force_device)]
+        tp_res = {"model": a.tp_model, "tp": world, "error": "no result"}
         try:
-            out["tp_scaling"] = run_tp_extra(pkg, torch, dist, a, rank, world, local_rank)
-        except Exception as e:  # noqa: BLE001 -- report, never lose the headline number
-            out["tp_scaling"] = {"model": a.tp_model, "tp": world, "error": repr(e)[:300]}
-        wd.cancel()
-        if done["printed"]:
-            return
-        done["printed"] = True
+            cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=a.tp_timeout)
+            for line in cp.stdout.splitlines():
+                if line.startswith("TP_LEG_RESULT "):
+                    tp_res = json.loads(line[len("TP_LEG_RESULT "):])
+            if "error" in tp_res and rank == 0:
+                tp_res["error"] = f"child exit {cp.returncode}: " + (cp.stderr.strip().splitlines() or ["?"])[-1][:300]
+        except subprocess.TimeoutExpired as e:
+            tail = (e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")).strip().splitlines()
+            tp_res = {"model": a.tp_model, "tp": world, "error": f"timed out after {a.tp_timeout} s: " + (tail[-1][:200] if tail else "")}
+        except Exception as e:  # noqa: BLE001
+            tp_res = {"model": a.tp_model, "tp": world, "error": repr(e)[:300]}
+        out["tp_scaling"] = tp_res
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
