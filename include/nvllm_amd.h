@@ -211,6 +211,9 @@ int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int mt, int nt,
 int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int hd, const int32_t* ctx_lens, int part_tokens,
                            int iters, float* us_per_call);
 
+/* debug: XCC_ID (which of the 8 XCDs) every workgroup of a (gx,gy,gz) grid lands on; out[linear workgroup id] */
+int nvllm_debug_xcc_map(nvllm_ctx* ctx, int gx, int gy, int gz, int threads, int32_t* out);
+
 /* device memory helpers so a non-HIP host (Rust, ctypes) can feed the nvllm_op_* calls */
 int nvllm_dev_alloc(nvllm_ctx* ctx, size_t bytes, void** out);
 int nvllm_dev_free(nvllm_ctx* ctx, void* p);

@@ -83,6 +83,7 @@ _SIGS = {
     "nvllm_op_synth_bf16": (C.c_int, [_vp, C.c_char_p, C.c_uint64, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_uint16)]),
     "nvllm_debug_gemm_bench": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "nvllm_debug_gemm_bench2": (C.c_int, [_vp] + [C.c_int] * 10 + [C.POINTER(C.c_float)]),
+    "nvllm_debug_xcc_map": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "nvllm_debug_attn_bench": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "nvllm_dev_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "nvllm_dev_free": (C.c_int, [_vp, _vp]),

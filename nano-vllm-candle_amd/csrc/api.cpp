@@ -1714,11 +1714,24 @@ extern "C" int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int
     return NVLLM_OK;
 }
 
+// which XCD each workgroup of a (gx,gy,gz) grid of `threads`-wide workgroups is dispatched to (out: gx*gy*gz ints)
+extern "C" int nvllm_debug_xcc_map(nvllm_ctx* ctx, int gx, int gy, int gz, int threads, int32_t* out) {
+    if (!ctx || !out || gx < 1 || gy < 1 || gz < 1 || threads < 64 || threads > 1024) return fail(ctx, NVLLM_EINVAL, "bad xcc_map arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    TmpBufs t;
+    int* d; const size_t n = (size_t)gx * gy * gz;
+    HIPCHK(ctx, t.get(&d, n));
+    HIPCHK(ctx, launch_xcc_map(gx, gy, gz, threads, d, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(out, d, n * 4, hipMemcpyDeviceToHost));
+    return NVLLM_OK;
+}
+
 // tuning aid, v2: mode 0 = slabs, 2 = SwiGLU epilogue (N = 2I); mt = m-tiles per workgroup (0 = planner);
 // `rot` weight copies are cycled so every launch streams cold HBM like the model does (1 = cache-warm).
 extern "C" int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int mt, int nt, int nw, int n_split, int mode,
                                        int rot, int iters, float* us_per_call) {
-    if (!ctx || !us_per_call || M < 1 || N % 32 || K % 128 || iters < 1 || rot < 1) return fail(ctx, NVLLM_EINVAL, "bad gemm_bench2 arguments");
+    if (!ctx || !us_per_call || M < 1 || (M > 128 && mode >= 10) || N % 32 || K % 128 || iters < 1 || rot < 1) return fail(ctx, NVLLM_EINVAL, "bad gemm_bench2 arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     GemmPlan p = mode == 2 ? plan_gemm_swiglu(M, N, K) : plan_gemm(M, N, K, 64);
@@ -1740,8 +1753,25 @@ extern "C" int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int 
     HIPCHK(ctx, t.get(&out, (size_t)p.n_split * M * N));
     HIPCHK(ctx, launch_synth_rowmajor_bf16(xh, 777, kSynthMatrix, 0, (int64_t)M * K, s));
     HIPCHK(ctx, launch_synth_rowmajor_bf16(xl, 778, kSynthMatrix, 0, (int64_t)M * K, s));
+    // modes 10/11/12: the row-parallel decode kernel with epilogue 0/1/2 (planner shapes; mt/nt/nw/n_split ignored)
+    float *resid = nullptr, *nextw = nullptr, *ssq = nullptr, *ssq_in = nullptr;
+    if (mode >= 10) {
+        if (!gemm_rowpar_ok(N, K, mode - 10, M)) return fail(ctx, NVLLM_EINVAL, "no row-parallel shape for N=%d K=%d epi=%d", N, K, mode - 10);
+        HIPCHK(ctx, t.get(&resid, (size_t)M * N)); HIPCHK(ctx, t.get(&nextw, (size_t)N));
+        HIPCHK(ctx, t.get(&ssq, (size_t)1024 * 128)); HIPCHK(ctx, t.get(&ssq_in, (size_t)128));
+        HIPCHK(ctx, hipMemsetAsync(resid, 0, (size_t)M * N * 4, s)); HIPCHK(ctx, hipMemsetAsync(nextw, 0, (size_t)N * 4, s));
+        HIPCHK(ctx, hipMemsetAsync(ssq_in, 0, 128 * 4, s));
+        float* o2; HIPCHK(ctx, t.get(&o2, (size_t)std::max(1, gemm_rowpar_splits(N, K, 2, M)) * M * N)); out = o2;
+    }
     auto go = [&](int i) -> hipError_t {
         const PackedW& w = ws[i % rot];
+        if (mode >= 10) {
+            RowParArgs ra;
+            ra.xh = xh; ra.xl = xl; ra.ldx = K; ra.M = M; ra.out = out; ra.resid_in = resid; ra.resid_out = resid; ra.next_w = nextw;
+            ra.oh = ah; ra.ol = al; ra.ssq = ssq; ra.ssq_stride = 128;
+            ra.rn.ssq = ssq_in; ra.rn.groups = 1; ra.rn.stride = 128; ra.rn.inv_h = 1.0f / K; ra.rn.eps = 1e-6f;
+            return launch_gemm_rowpar(ra, w, mode - 10, s);
+        }
         return mode == 2 ? launch_gemm_swiglu(p, xh, xl, K, w, M, ah, al, s) : launch_gemm(p, xh, xl, K, w, out, M, s);
     };
     for (int i = 0; i < 3; ++i) HIPCHK(ctx, go(i));

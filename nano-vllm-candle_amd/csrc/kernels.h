@@ -229,6 +229,8 @@ hipError_t launch_kv_write_plain(const float* k, const float* v, int rows, const
 struct PrefetchRange { const void* ptr; size_t bytes; };
 // touch every 128-byte line of the ranges (device array) so they are cache-resident for the next consumer
 hipError_t launch_prefetch_ranges(const PrefetchRange* d_ranges, int n_ranges, unsigned* sink, int blocks_x, hipStream_t s);
+// debug: XCC_ID of every workgroup of a (gx,gy,gz) grid, out[linear workgroup id]
+hipError_t launch_xcc_map(int gx, int gy, int gz, int threads, int* out, hipStream_t s);
 // token feedback for nvllm_decode_next: ids[i] = next[i]; pos[i] += 1
 hipError_t launch_advance_decode(uint32_t* ids, const uint32_t* next, int* pos, int n, hipStream_t s);
 

@@ -797,6 +797,170 @@ __global__ void __launch_bounds__(NWN * NWK * 64) gemm_rowpar_kernel(RowParArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Row-parallel projection, register-direct form (decode, K <= 4096): one workgroup = 16 rows x NT n-tiles for
+// the WHOLE K, its NWK waves each own TK k-tiles of every n-tile.  No x image in LDS and no phases: a wave's
+// weight fragments (NT*TK KiB) and its own x fragments (2*TK KiB, read by no other wave of the workgroup) all
+// go HBM/L2 -> VGPR in one round trip, the K slices meet in LDS once, wave t finishes n-tile t.
+// Measured on MI355X (tools/probe_l2.py, weights L2-warm): every LDS phase of the staged kernel above costs
+// 1.5-2 us of dependent latency; this form has none.  Epilogues as gemm_rowpar_kernel.
+// ---------------------------------------------------------------------------------------------------
+template <int NT, int NWK, int TK, int EPI>
+__global__ void __launch_bounds__(NWK * 64) gemm_rowdir_kernel(RowParArgs a, const uint4* __restrict__ wp, int N, int KT) {
+    static_assert(NT <= NWK, "wave t finishes n-tile t");
+    constexpr int NR = 16;
+    // sred: [NT][16] ssq partials (epilogue 0) or [4][16] rinv partials (epilogue 1)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                                // [NWK][NT][64]
+    float* sred = reinterpret_cast<float*>(smem_raw + (size_t)NWK * NT * 1024);     // [NS][16]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int ntiles = N >> 4;
+    const int tile0 = (int)blockIdx.x * NT;
+    const int m0 = blockIdx.z * NR;
+    const int M = a.M;
+    const int k0 = wave * TK;
+
+    uint4 w[NT][TK];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int nt = min(tile0 + t, ntiles - 1);
+#pragma unroll
+        for (int j = 0; j < TK; ++j) w[t][j] = wp[((size_t)nt * KT + k0 + j) * 64 + lane];
+    }
+    const int xrow = min(m0 + l15, M - 1);
+    uint4 xh[TK], xl[TK];
+    {
+        const size_t xo = (size_t)xrow * a.ldx + (size_t)k0 * 32 + grp * 8;
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+            xh[j] = *reinterpret_cast<const uint4*>(a.xh + xo + j * 32);
+            xl[j] = *reinterpret_cast<const uint4*>(a.xl + xo + j * 32);
+        }
+    }
+    // epilogue operands of the finishing waves (independent of the product): behind the streaming loads
+    const int ntile = min(tile0 + wave, ntiles - 1);
+    const bool fin = wave < NT && (tile0 + wave) < ntiles;
+    const int row = m0 + l15;
+    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f), nw4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (EPI == 0) {
+        if (fin) {
+            nw4 = *reinterpret_cast<const float4*>(a.next_w + (size_t)ntile * 16 + grp * 4);
+            if (row < M) r4 = *reinterpret_cast<const float4*>(a.resid_in + (size_t)row * N + (size_t)ntile * 16 + grp * 4);
+        }
+    }
+    if constexpr (EPI == 1) rownorm_partials<NR>(a.rn, m0, M, sred);
+    __builtin_amdgcn_sched_barrier(0);  // every load above is issued before the first use below (one round trip)
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < TK; ++j) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, xh[j]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, xl[j]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16x8 wv = __builtin_bit_cast(bf16x8, w[t][j]);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, bl, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) red[(size_t)(wave * NT + t) * 64 + lane] = acc[t];
+    __syncthreads();
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    if (wave < NT) {
+#pragma unroll
+        for (int k = 0; k < NWK; ++k) {
+            const f32x4 v = red[(size_t)(k * NT + wave) * 64 + lane];
+            sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+        }
+    }
+    if constexpr (EPI == 0) {
+        if (wave < NT) {
+            float ssq_part = 0.f;
+            if (fin && row < M) {
+                const size_t o = (size_t)row * N + (size_t)ntile * 16 + grp * 4;
+                const float s0 = sum[0] + r4.x, s1 = sum[1] + r4.y, s2 = sum[2] + r4.z, s3 = sum[3] + r4.w;
+                *reinterpret_cast<float4*>(a.resid_out + o) = make_float4(s0, s1, s2, s3);
+                uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
+                split_bf16(s0 * nw4.x, h0, l0); split_bf16(s1 * nw4.y, h1, l1); split_bf16(s2 * nw4.z, h2, l2); split_bf16(s3 * nw4.w, h3, l3);
+                *reinterpret_cast<uint2*>(a.oh + o) = make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
+                *reinterpret_cast<uint2*>(a.ol + o) = make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
+                ssq_part = s0 * s0 + s1 * s1 + s2 * s2 + s3 * s3;
+            }
+            ssq_part += __shfl_xor(ssq_part, 16);
+            ssq_part += __shfl_xor(ssq_part, 32);
+            if constexpr (NT == 1) {
+                if (grp == 0 && row < M) a.ssq[(size_t)blockIdx.x * a.ssq_stride + row] = ssq_part;
+            } else {
+                if (grp == 0) sred[wave * NR + l15] = ssq_part;
+            }
+        }
+        if constexpr (NT > 1) {
+            __syncthreads();
+            if (wave == 0 && grp == 0 && row < M) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < NT; ++k) t += sred[k * NR + l15];
+                a.ssq[(size_t)blockIdx.x * a.ssq_stride + row] = t;
+            }
+        }
+    } else if constexpr (EPI == 1) {
+        static_assert(EPI != 1 || (NT % 2 == 0), "SwiGLU epilogue pairs two n-tiles");
+        // odd tiles (up) park their sums in slot [0][t]; the even (gate) wave of the pair finishes
+        __syncthreads();  // every finishing wave is done reading red
+        if (wave < NT && (wave & 1)) red[(size_t)wave * 64 + lane] = sum;
+        __syncthreads();
+        const int pair = (tile0 + wave) >> 1;  // activation feature tile
+        if (wave < NT && !(wave & 1) && (tile0 + wave + 1) < ntiles && row < M) {
+            const int I = N >> 1;
+            const f32x4 up = red[(size_t)(wave + 1) * 64 + lane];
+            const float ri = rownorm_rinv_lds<NR>(a.rn, sred, l15);
+            uint16_t h[4], l[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float g = sum[r] * ri, u = up[r] * ri;
+                split_bf16((g / (1.0f + __expf(-g))) * u, h[r], l[r]);
+            }
+            const size_t o = (size_t)row * I + (size_t)pair * 16 + grp * 4;
+            *reinterpret_cast<uint2*>(a.oh + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+            *reinterpret_cast<uint2*>(a.ol + o) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+        }
+    } else {
+        if (fin && row < M)
+            *reinterpret_cast<float4*>(a.out + (size_t)row * N + (size_t)ntile * 16 + grp * 4) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+    }
+}
+
+// shape of the register-direct kernel for (N, K, epi, M): nt == 0 -> not applicable
+struct RowDirShape { int nt, nwk, tk; };
+static RowDirShape rowdir_shape(int N, int K, int epi, int M) {
+    RowDirShape none{0, 0, 0};
+    static const bool off = getenv("NVLLM_NO_ROWDIR") != nullptr;
+    if (off || N % 16 || K % 32 || M > 128) return none;
+    const int KT = K / 32, ntiles = N / 16;
+    if (KT % 16 || KT / 16 < 2 || KT / 16 > 8 || (KT / 16) % 2) return none;  // K in {1024, 2048, 3072, 4096}
+    const int tk = KT / 16;
+    int nt;
+    if (epi == 0) {
+        nt = 1;
+        while ((ntiles + nt - 1) / nt > 64) nt *= 2;  // deferred-norm consumers sum <= 64 ssq groups
+        if (nt > 4 || nt * tk > 16 || (nt == 2 && tk == 8)) return none;
+    } else if (epi == 1) {
+        nt = (ntiles % 6 == 0 && tk == 2) ? 6 : 4;
+        if (ntiles % 2 || nt * tk > 16) return none;
+    } else {
+        nt = 4;
+        if (nt * tk > 16) nt = 2;
+        if (nt * tk > 16) return none;
+    }
+    // weights are streamed once per row block: big matrices belong to the 64-row kernel
+    if ((size_t)N * K * 2 >= ((size_t)24 << 20) && M > 16) return none;
+    return RowDirShape{nt, 16, tk};
+}
+
 struct RowParShape { int mt, nwn, nwk, tpw, ph, ns; };
 // Decomposition of y[M,N] = x.W^T for the row-parallel kernel (false: use the generic kernel).
 //   small matrices: 16 rows per workgroup (row blocks re-read the weights through L2), whole K in one workgroup;
@@ -834,13 +998,51 @@ static bool rowpar_shape(int N, int K, int epi, int M, RowParShape& sh) {
             }
     return false;
 }
-bool gemm_rowpar_supported(int N, int K) { RowParShape sh; return rowpar_shape(N, K, 0, 64, sh); }
+bool gemm_rowpar_supported(int N, int K) {
+    RowParShape sh;
+    return (rowdir_shape(N, K, 0, 64).nt || rowpar_shape(N, K, 0, 64, sh)) && gemm_rowpar_groups(N, K) <= 64;
+}
 bool gemm_rowpar_ok(int N, int K, int epi, int M) {
+    if (rowdir_shape(N, K, epi, M).nt) return true;
     RowParShape sh;
     return rowpar_shape(N, K, epi, M, sh) && !(epi == 1 && sh.nwn % 2);
 }
-int gemm_rowpar_groups(int N, int K) { RowParShape sh; if (!rowpar_shape(N, K, 0, 64, sh)) return 0; return (N / 16 + sh.nwn - 1) / sh.nwn; }
-int gemm_rowpar_splits(int N, int K, int epi, int M) { RowParShape sh; return rowpar_shape(N, K, epi, M, sh) ? sh.ns : 0; }
+// ssq groups the epilogue-0 kernel leaves (independent of M: the fused path never exceeds 128 rows)
+int gemm_rowpar_groups(int N, int K) {
+    const RowDirShape d = rowdir_shape(N, K, 0, 64);
+    if (d.nt) return (N / 16 + d.nt - 1) / d.nt;
+    RowParShape sh;
+    if (!rowpar_shape(N, K, 0, 64, sh)) return 0;
+    return (N / 16 + sh.nwn - 1) / sh.nwn;
+}
+int gemm_rowpar_splits(int N, int K, int epi, int M) {
+    if (rowdir_shape(N, K, epi, M).nt) return 1;
+    RowParShape sh;
+    return rowpar_shape(N, K, epi, M, sh) ? sh.ns : 0;
+}
+
+template <int NT, int NWK, int TK, int EPI>
+static hipError_t rowdir_launch_t(const RowParArgs& a, const PackedW& w, hipStream_t s) {
+    const size_t lds = (size_t)NWK * NT * 1024 + (size_t)(NT > 4 ? NT : 4) * 16 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowdir_kernel<NT, NWK, TK, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((w.N / 16 + NT - 1) / NT, 1, (a.M + 15) / 16);
+    gemm_rowdir_kernel<NT, NWK, TK, EPI><<<grid, NWK * 64, lds, s>>>(a, w.data, w.N, w.K / 32);
+    return hipGetLastError();
+}
+template <int EPI>
+static hipError_t rowdir_dispatch(const RowDirShape& d, const RowParArgs& a, const PackedW& w, hipStream_t s) {
+#define NVLLM_RD(NT_, TK_) if (d.nt == NT_ && d.tk == TK_) return rowdir_launch_t<NT_, 16, TK_, EPI>(a, w, s);
+    if constexpr (EPI == 0) { NVLLM_RD(1, 2) NVLLM_RD(1, 4) NVLLM_RD(1, 6) NVLLM_RD(1, 8) NVLLM_RD(2, 2) NVLLM_RD(2, 4) NVLLM_RD(2, 6) NVLLM_RD(4, 2) NVLLM_RD(4, 4) }
+    if constexpr (EPI == 1) { NVLLM_RD(6, 2) NVLLM_RD(4, 2) NVLLM_RD(4, 4) }
+    if constexpr (EPI == 2) { NVLLM_RD(4, 2) NVLLM_RD(4, 4) NVLLM_RD(2, 6) NVLLM_RD(2, 8) }
+#undef NVLLM_RD
+    return hipErrorNotSupported;
+}
 
 template <int MT, int NWN, int NWK, int TPW, int PH, int EPI>
 static hipError_t rowpar_launch_t(const RowParShape& sh, const RowParArgs& a, const PackedW& w, hipStream_t s) {
@@ -877,6 +1079,13 @@ static hipError_t rowpar_dispatch(const RowParShape& sh, const RowParArgs& a, co
 }
 
 hipError_t launch_gemm_rowpar(const RowParArgs& a, const PackedW& w, int epi, hipStream_t s) {
+    if (const RowDirShape d = rowdir_shape(w.N, w.K, epi, a.M); d.nt) {
+        if (a.M <= 0) return hipSuccess;
+        if (epi == 0) return rowdir_dispatch<0>(d, a, w, s);
+        if (epi == 1) return rowdir_dispatch<1>(d, a, w, s);
+        if (epi == 2) return rowdir_dispatch<2>(d, a, w, s);
+        return hipErrorInvalidValue;
+    }
     RowParShape sh;
     if (!rowpar_shape(w.N, w.K, epi, a.M, sh)) return hipErrorNotSupported;
     if (epi == 1 && sh.nwn % 2) return hipErrorNotSupported;
@@ -1786,6 +1995,17 @@ hipError_t launch_prefetch_ranges(const PrefetchRange* d_ranges, int n_ranges, u
     if (n_ranges <= 0) return hipSuccess;
     dim3 grid(std::max(1, blocks_x), std::min(n_ranges, 64));
     prefetch_ranges_kernel<<<grid, 256, 0, s>>>(d_ranges, n_ranges, sink);
+    return hipGetLastError();
+}
+
+// which XCD (accelerator complex die) each workgroup of a grid lands on: out[linear workgroup id] = XCC_ID
+__global__ void xcc_map_kernel(int* out) {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    if (threadIdx.x == 0) out[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] = (int)(x & 15u);
+}
+hipError_t launch_xcc_map(int gx, int gy, int gz, int threads, int* out, hipStream_t s) {
+    xcc_map_kernel<<<dim3(gx, gy, gz), threads, 0, s>>>(out);
     return hipGetLastError();
 }
 
