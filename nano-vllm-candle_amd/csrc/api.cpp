@@ -701,18 +701,26 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->red, R * m->H);
     if (!rc) rc = dmalloc(ctx, &m->logits, (size_t)max_seqs * m->cfg.vocab_size);  // full vocab: TP gathers here
     if (!rc) rc = dmalloc(ctx, &m->d_maxval, (size_t)max_seqs * std::max(1, ctx->tp_size) * 2);
-    if (!rc) rc = dmalloc(ctx, &m->xh, R * wide);
-    if (!rc) rc = dmalloc(ctx, &m->xl, R * wide);
+    const size_t R16 = (R + 15) / 16 * 16;  // packed activation planes are read in whole 16-row blocks
+    if (!rc) rc = dmalloc(ctx, &m->xh, R16 * wide);
+    if (!rc) rc = dmalloc(ctx, &m->xl, R16 * wide);
+    if (!rc) { HIPCHK(ctx, hipMemsetAsync(m->xh, 0, R16 * wide * 2, ctx->stream)); HIPCHK(ctx, hipMemsetAsync(m->xl, 0, R16 * wide * 2, ctx->stream)); }
     m->fused_ok = ctx->tp_size == 1 && gemm_rowpar_supported(m->H, m->nh_l * m->hd) && gemm_rowpar_supported(m->H, m->I_l);
     {
         const size_t g = std::max<size_t>({(size_t)1, (size_t)gemm_rowpar_groups(m->H, m->nh_l * m->hd), (size_t)gemm_rowpar_groups(m->H, m->I_l)});
         if (!rc) rc = dmalloc(ctx, &m->ssqA, g * kFusedMaxRows);
         if (!rc) rc = dmalloc(ctx, &m->ssqB, g * kFusedMaxRows);
     }
-    if (!rc) rc = dmalloc(ctx, &m->ctxh, R * (size_t)m->nh_l * m->hd);
-    if (!rc) rc = dmalloc(ctx, &m->ctxl, R * (size_t)m->nh_l * m->hd);
-    if (!rc) rc = dmalloc(ctx, &m->xh2, R * (size_t)m->I_l);
-    if (!rc) rc = dmalloc(ctx, &m->xl2, R * (size_t)m->I_l);
+    if (!rc) rc = dmalloc(ctx, &m->ctxh, R16 * (size_t)m->nh_l * m->hd);
+    if (!rc) rc = dmalloc(ctx, &m->ctxl, R16 * (size_t)m->nh_l * m->hd);
+    if (!rc) rc = dmalloc(ctx, &m->xh2, R16 * (size_t)m->I_l);
+    if (!rc) rc = dmalloc(ctx, &m->xl2, R16 * (size_t)m->I_l);
+    if (!rc) {
+        HIPCHK(ctx, hipMemsetAsync(m->ctxh, 0, R16 * (size_t)m->nh_l * m->hd * 2, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(m->ctxl, 0, R16 * (size_t)m->nh_l * m->hd * 2, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(m->xh2, 0, R16 * (size_t)m->I_l * 2, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(m->xl2, 0, R16 * (size_t)m->I_l * 2, ctx->stream));
+    }
     if (!rc) rc = dmalloc(ctx, &m->d_next, (size_t)max_seqs * (ctx->tp_size + 1));
     if (!rc) rc = dmalloc(ctx, &m->attn_po, (size_t)max_seqs * m->nh_l * kAttnMaxParts * m->hd);
     if (!rc) rc = dmalloc(ctx, &m->attn_pml, (size_t)max_seqs * m->nh_l * kAttnMaxParts * 2);
@@ -826,10 +834,14 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
     m->tap_rows = R;
     RowNorm rn;  // the norm pending on xh/xl
     rn.stride = kFusedMaxRows; rn.inv_h = 1.0f / (float)H; rn.eps = eps;
+    // every GEMM of the layer on the register-direct kernel: the activation planes stay in fragment order
+    static const bool no_xpack = getenv("NVLLM_NO_XPACK") != nullptr;
+    const int packed = !no_xpack && gemm_rowdir_ok(NQ, H, 2, R) && gemm_rowdir_ok(H, KO, 0, R) &&
+                       gemm_rowdir_ok(2 * m->I_l, H, 1, R) && gemm_rowdir_ok(H, m->I_l, 0, R);
     {   // layer 0 input: residual = embedding row, x' = ln1 (.) row, ssq (qwen3.rs:382-386, 465-468)
         NormArgs na;
         na.ids = m->d_ids; na.embed = m->embed; na.weight = m->layers[0].ln1; na.eps = eps; na.H = H;
-        na.xh = m->xh; na.xl = m->xl; na.residual_out = m->resid; na.ssq_out = m->ssqB;
+        na.xh = m->xh; na.xl = m->xl; na.residual_out = m->resid; na.ssq_out = m->ssqB; na.out_packed = packed;
         PROF(m, PROF_NORM, launch_add_rmsnorm(na, R, s));
         rn.ssq = m->ssqB; rn.groups = 1;
     }
@@ -838,7 +850,7 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
         QkvArgs qa;
         {   // QKV projection: whole-K row-parallel kernel (one f32 result, no slabs) when the shape allows
             RowParArgs rq;
-            rq.xh = m->xh; rq.xl = m->xl; rq.ldx = H; rq.out = m->slabs; rq.M = R;
+            rq.xh = m->xh; rq.xl = m->xl; rq.ldx = H; rq.out = m->slabs; rq.M = R; rq.x_packed = packed;
             if (gemm_rowpar_ok(NQ, H, 2, R)) {
                 PROF(m, PROF_GEMM, launch_gemm_rowpar(rq, w.qkv, 2, s));
                 qa.n_slabs = 1;
@@ -859,7 +871,7 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
         AttnArgs aa;
         aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
         aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
-        aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->ctxh; aa.out_lo = m->ctxl;
+        aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->ctxh; aa.out_lo = m->ctxl; aa.out_packed = packed;
         if (qt == 1) aa.tile_order = m->d_tile_order;
         if (fuse_qk) {
             aa.qkv = qa.qkv; aa.n_slabs = qa.n_slabs; aa.slab_stride = qa.slab_stride; aa.ldqkv = NQ; aa.qn = w.qn; aa.kn = w.kn;
@@ -875,12 +887,14 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
         RowParArgs ra;
         ra.xh = m->ctxh; ra.xl = m->ctxl; ra.ldx = KO; ra.resid_in = m->resid; ra.resid_out = m->resid; ra.next_w = w.ln2;
         ra.oh = m->xh; ra.ol = m->xl; ra.ssq = m->ssqA; ra.ssq_stride = kFusedMaxRows; ra.M = R;
+        ra.x_packed = packed; ra.o_packed = packed;
         PROF(m, PROF_GEMM, launch_gemm_rowpar(ra, w.o, 0, s));
         rn.ssq = m->ssqA; rn.groups = gemm_rowpar_groups(H, KO);
         // gate/up + SiLU*mul (qwen3.rs:324-325), scaled by the pending norm's rinv
         {
             RowParArgs rg;
             rg.xh = m->xh; rg.xl = m->xl; rg.ldx = H; rg.oh = m->xh2; rg.ol = m->xl2; rg.M = R; rg.rn = rn;
+            rg.x_packed = packed; rg.o_packed = packed;
             if (gemm_rowpar_ok(2 * m->I_l, H, 1, R)) {
                 PROF(m, PROF_GEMM, launch_gemm_rowpar(rg, w.gu, 1, s));
             } else {
@@ -894,6 +908,7 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
         rd.xh = m->xh2; rd.xl = m->xl2; rd.ldx = m->I_l; rd.resid_in = m->resid; rd.resid_out = m->resid;
         rd.next_w = l + 1 < m->L ? m->layers[l + 1].ln1 : m->norm;
         rd.oh = m->xh; rd.ol = m->xl; rd.ssq = m->ssqB; rd.ssq_stride = kFusedMaxRows; rd.M = R;
+        rd.x_packed = packed; rd.o_packed = packed && l + 1 < m->L;  // the LM head (chunked kernel) reads row-major planes
         PROF(m, PROF_GEMM, launch_gemm_rowpar(rd, w.down, 0, s));
         rn.ssq = m->ssqB; rn.groups = gemm_rowpar_groups(H, m->I_l);
     }

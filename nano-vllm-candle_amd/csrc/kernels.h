@@ -46,6 +46,14 @@ hipError_t launch_split_hilo(const float* x, bf16_bits* hi, bf16_bits* lo, int64
 // consumer is linear in x, it applies rinv[row] = 1/sqrt(sum_g ssq[g][row]/H + eps) to its OUTPUT instead:
 //   norm(s).W^T = rinv * ((w (.) s).W^T)          (layernorm.rs:55-57 semantics, f32)
 // ssq == nullptr means the activations are already normalised (rinv = 1).
+// Packed activation layout (MFMA B-fragment order, one 1 KiB wave-load per 16 rows x 32 k):
+//   [rows/16][K/32][64 lanes][8] bf16, lane = ((k % 32) / 8) * 16 + row % 16.   KT = K / 32.
+// The fused decode path keeps its hi/lo activation planes in this order when every consumer reads fragments
+// (row-major planes cost the register-direct GEMMs 3x per byte: 16 half-used lines per wave-load).
+__host__ __device__ inline size_t xpack_off(int row, int k, int KT) {
+    return (((size_t)(row >> 4) * KT + (k >> 5)) << 9) + (size_t)(((((k & 31) >> 3) << 4) + (row & 15)) << 3) + (k & 7);
+}
+
 struct RowNorm {
     const float* ssq = nullptr;  // [groups][stride]
     int groups = 0;
@@ -96,6 +104,7 @@ struct NormArgs {
     bf16_bits* xl = nullptr;
     float* y = nullptr;
     float* ssq_out = nullptr;         // prep mode (fused decode path): outputs are w (.) s (no 1/rms) and ssq_out[r] = sum s^2
+    int out_packed = 0;               // xh/xl in xpack_off order
 };
 hipError_t launch_add_rmsnorm(const NormArgs& a, int rows, hipStream_t s);
 
@@ -144,6 +153,7 @@ struct AttnArgs {
     bf16_bits* out_hi = nullptr;       // [rows][nh_l*hd]
     bf16_bits* out_lo = nullptr;
     float* out_f32 = nullptr;          // optional f32 copy (fine-seam op)
+    int out_packed = 0;                // out_hi/out_lo in xpack_off order
     // fused decode prologue (qkv != nullptr; every tile must be a single row): the kernel sums the QKV GEMM's
     // slabs itself, applies q/k RMSNorm + RoPE, writes the row's K/V into the cache, then attends
     const float* qkv = nullptr;        // [n_slabs][rows][ldqkv]
@@ -184,8 +194,11 @@ struct RowParArgs {
     // epilogue 2 (plain): out f32 [M][N]
     float* out = nullptr;
     RowNorm rn;
+    int x_packed = 0, o_packed = 0;  // xh/xl resp. oh/ol in xpack_off order (register-direct kernel only)
 };
 bool gemm_rowpar_supported(int N, int K);
+// true when launch_gemm_rowpar would run the register-direct kernel (the one that accepts packed planes)
+bool gemm_rowdir_ok(int N, int K, int epi, int M);
 bool gemm_rowpar_ok(int N, int K, int epi, int M);
 int gemm_rowpar_splits(int N, int K, int epi, int M);  // f32 slabs the plain epilogue leaves (1 = complete sums)
 int gemm_rowpar_groups(int N, int K);

@@ -831,11 +831,15 @@ __global__ void __launch_bounds__(NWK * 64) gemm_rowdir_kernel(RowParArgs a, con
     const int xrow = min(m0 + l15, M - 1);
     uint4 xh[TK], xl[TK];
     {
-        const size_t xo = (size_t)xrow * a.ldx + (size_t)k0 * 32 + grp * 8;
+        // row-major: 16 rows x 64 B per wave-load; packed: one contiguous 1 KiB fragment (rows >= M of the last
+        // block hold stale finite-or-not values whose products are never stored)
+        const size_t xo = a.x_packed ? (((size_t)(m0 >> 4) * KT + k0) << 9) + (size_t)lane * 8
+                                     : (size_t)xrow * a.ldx + (size_t)k0 * 32 + grp * 8;
+        const int xs = a.x_packed ? 512 : 32;
 #pragma unroll
         for (int j = 0; j < TK; ++j) {
-            xh[j] = *reinterpret_cast<const uint4*>(a.xh + xo + j * 32);
-            xl[j] = *reinterpret_cast<const uint4*>(a.xl + xo + j * 32);
+            xh[j] = *reinterpret_cast<const uint4*>(a.xh + xo + j * xs);
+            xl[j] = *reinterpret_cast<const uint4*>(a.xl + xo + j * xs);
         }
     }
     // epilogue operands of the finishing waves (independent of the product): behind the streaming loads
@@ -886,8 +890,9 @@ __global__ void __launch_bounds__(NWK * 64) gemm_rowdir_kernel(RowParArgs a, con
                 *reinterpret_cast<float4*>(a.resid_out + o) = make_float4(s0, s1, s2, s3);
                 uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
                 split_bf16(s0 * nw4.x, h0, l0); split_bf16(s1 * nw4.y, h1, l1); split_bf16(s2 * nw4.z, h2, l2); split_bf16(s3 * nw4.w, h3, l3);
-                *reinterpret_cast<uint2*>(a.oh + o) = make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
-                *reinterpret_cast<uint2*>(a.ol + o) = make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
+                const size_t ob = a.o_packed ? xpack_off(row, ntile * 16 + grp * 4, N >> 5) : o;
+                *reinterpret_cast<uint2*>(a.oh + ob) = make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
+                *reinterpret_cast<uint2*>(a.ol + ob) = make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
                 ssq_part = s0 * s0 + s1 * s1 + s2 * s2 + s3 * s3;
             }
             ssq_part += __shfl_xor(ssq_part, 16);
@@ -924,7 +929,7 @@ __global__ void __launch_bounds__(NWK * 64) gemm_rowdir_kernel(RowParArgs a, con
                 const float g = sum[r] * ri, u = up[r] * ri;
                 split_bf16((g / (1.0f + __expf(-g))) * u, h[r], l[r]);
             }
-            const size_t o = (size_t)row * I + (size_t)pair * 16 + grp * 4;
+            const size_t o = a.o_packed ? xpack_off(row, pair * 16 + grp * 4, I >> 5) : (size_t)row * I + (size_t)pair * 16 + grp * 4;
             *reinterpret_cast<uint2*>(a.oh + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
             *reinterpret_cast<uint2*>(a.ol + o) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
         }
@@ -1015,6 +1020,7 @@ int gemm_rowpar_groups(int N, int K) {
     if (!rowpar_shape(N, K, 0, 64, sh)) return 0;
     return (N / 16 + sh.nwn - 1) / sh.nwn;
 }
+bool gemm_rowdir_ok(int N, int K, int epi, int M) { return rowdir_shape(N, K, epi, M).nt != 0; }
 int gemm_rowpar_splits(int N, int K, int epi, int M) {
     if (rowdir_shape(N, K, epi, M).nt) return 1;
     RowParShape sh;
@@ -1086,6 +1092,7 @@ hipError_t launch_gemm_rowpar(const RowParArgs& a, const PackedW& w, int epi, hi
         if (epi == 2) return rowdir_dispatch<2>(d, a, w, s);
         return hipErrorInvalidValue;
     }
+    if (a.x_packed || a.o_packed) return hipErrorNotSupported;  // packed planes: register-direct kernel only
     RowParShape sh;
     if (!rowpar_shape(w.N, w.K, epi, a.M, sh)) return hipErrorNotSupported;
     if (epi == 1 && sh.nwn % 2) return hipErrorNotSupported;
@@ -1155,10 +1162,9 @@ __global__ void __launch_bounds__(256) add_rmsnorm_kernel(NormArgs a) {
             if (a.xh) {
                 uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
                 split_bf16(y0, h0, l0); split_bf16(y1, h1, l1); split_bf16(y2, h2, l2); split_bf16(y3, h3, l3);
-                *reinterpret_cast<uint2*>(a.xh + (size_t)r * H + (size_t)i * 4) =
-                    make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
-                *reinterpret_cast<uint2*>(a.xl + (size_t)r * H + (size_t)i * 4) =
-                    make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
+                const size_t xo = a.out_packed ? xpack_off(r, i * 4, H >> 5) : (size_t)r * H + (size_t)i * 4;
+                *reinterpret_cast<uint2*>(a.xh + xo) = make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
+                *reinterpret_cast<uint2*>(a.xl + xo) = make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
             }
         }
     }
@@ -1622,10 +1628,9 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
             if (a.out_hi) {
                 uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
                 split_bf16(y0, h0, l0); split_bf16(y1, h1, l1); split_bf16(y2, h2, l2); split_bf16(y3, h3, l3);
-                *reinterpret_cast<uint2*>(a.out_hi + base + d * 16) =
-                    make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
-                *reinterpret_cast<uint2*>(a.out_lo + base + d * 16) =
-                    make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
+                const size_t xo = a.out_packed ? xpack_off(my_row[t], my_head * HD + d * 16 + grp * 4, ldq >> 5) : base + d * 16;
+                *reinterpret_cast<uint2*>(a.out_hi + xo) = make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
+                *reinterpret_cast<uint2*>(a.out_lo + xo) = make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
             }
         }
         if (n_parts > 1 && wave == 0 && grp == 0) {
@@ -1672,8 +1677,9 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(AttnArgs a, int rows)
         if (a.out_hi) {
             uint16_t h, l;
             split_bf16(y, h, l);
-            a.out_hi[base + j] = h;
-            a.out_lo[base + j] = l;
+            const size_t xo = a.out_packed ? xpack_off(row, head * HD + lane * PER + j, (a.nh_l * HD) >> 5) : base + j;
+            a.out_hi[xo] = h;
+            a.out_lo[xo] = l;
         }
     }
 }

@@ -241,6 +241,29 @@ def test_qwen3_0_6b_shapes_vs_oracle(pkg, ctx, oracle):
     assert worst < LOGITS_TOL, worst
 
 
+def test_0_6b_layer_shapes_fused_decode_vs_oracle(pkg, ctx, oracle):
+    # the fused decode path at the REAL layer shapes (H 1024, 16/8 heads of 128, I 3072: register-direct GEMMs on
+    # packed activation planes) on a 2-layer, 8192-token-vocabulary model the oracle finishes in seconds:
+    # one sequence (1 row), then 20 sequences (two 16-row blocks, the second one partial)
+    cfg = pkg.Qwen3Config.tiny(vocab_size=8192, hidden_size=1024, head_dim=128, num_hidden_layers=2,
+                               num_attention_heads=16, num_key_value_heads=8, intermediate_size=3072)
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
+    m.kv_alloc(32, 24, 1024)
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(0)
+    rng = np.random.default_rng(5)
+    for sids, lens in (([0], [16]), (list(range(1, 21)), rng.integers(3, 41, 20).tolist())):
+        seqs = [rng.integers(0, cfg.vocab_size, int(n)).tolist() for n in lens]
+        for step in range(3):
+            ids, lg = m.step(sids, seqs, step == 0, want_logits=True)
+            rid, rlg = om.run_greedy(seqs)
+            assert row_rel_err(lg, rlg) < LOGITS_TOL, (len(sids), step)
+            srt = np.sort(rlg, axis=1)
+            clear = (srt[:, -1] - srt[:, -2]) / np.abs(rlg).max(axis=1) > 2 * LOGITS_TOL
+            assert (ids == rid)[clear].all(), (len(sids), step)
+            for s_, t in zip(seqs, rid):
+                s_.append(int(t))
+
+
 def test_full_size_batch64_properties(pkg, ctx):
     # BASELINE configs[2] size (0.6B, 64 live sequences): size-independent properties
     cfg = pkg.Qwen3Config.qwen3_0_6b()
