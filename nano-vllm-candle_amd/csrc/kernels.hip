@@ -1357,18 +1357,8 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
 #pragma unroll
         for (int d = 0; d < DT; ++d) vf[d] = *reinterpret_cast<const uint4*>(vb + d * 512 + lane * 8);
     };
-    // decode register sets (QT == 1); set A may be prefetched before the fused prologue
+    // decode register sets (QT == 1): two 32-token tiles (32 KiB) of this wave are in flight at any time
     uint4 kaA[DC], kbA[DC], vfA[DT], kaB[DC], kbB[DC], vfB[DT];
-    bool pre_loaded = false;
-    if constexpr (FUSED) {
-        // start this wave's first tile before the prologue unless it is the tile the new token goes into
-        // (that one must be read after wave 0 has written it)
-        const int kt0 = min(t_begin + wave, t_end - 1);
-        if (false && kt0 != (pmax >> 5)) {  // A/B on MI355X: loading before the prologue is 0.8 % slower (vmcnt is in order)
-            load_tile(kt0, kaA, kbA, vfA);
-            pre_loaded = true;
-        }
-    }
     f16x8 qh[QT][DC], ql[QT][DC];
     if constexpr (FUSED) {
         // Decode, fused prologue (replaces a separate launch): this workgroup is the only consumer of q heads
@@ -1410,7 +1400,14 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
             *reinterpret_cast<float4*>(&sn[c][0]) = *reinterpret_cast<const float4*>(a.sin + o);
             *reinterpret_cast<float4*>(&sn[c][4]) = *reinterpret_cast<const float4*>(a.sin + o + 4);
         }
-        const float ri = rownorm_rinv_wave(a.rn, row, lane);  // deferred input norm of this row
+        // deferred input norm of this row: lane g loads group g (groups <= 64), summed below
+        const float ssq_g = (a.rn.ssq && lane < a.rn.groups) ? a.rn.ssq[(size_t)lane * a.rn.stride + row] : 0.f;
+        // This wave's first KV tile goes in flight BEHIND the prologue's own loads (vmcnt retires in order, so the
+        // prologue never waits for it) and lands while it computes; a second set would push the kernel to one wave
+        // per SIMD.  A first tile that holds the new token's slot is read again after the barrier below
+        // (contexts of <= 4 tiles only).
+        load_tile(min(t_begin + wave, t_end - 1), kaA, kbA, vfA);
+        const float ri = a.rn.ssq ? 1.0f / sqrtf(wave_sum(ssq_g) * a.rn.inv_h + a.rn.eps) : 1.0f;
         for (int sl = 1; sl < a.n_slabs; ++sl) {  // split-K partials of a generic QKV GEMM (rare on this path)
             const size_t so = (size_t)sl * a.slab_stride;
             if (wave == 0) { kx1 += pk[so + ln]; kx2 += pk[so + ln + half]; vx1 += pv[so + ln]; vx2 += pv[so + ln + half]; }
@@ -1546,17 +1543,24 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
         // Each wave takes every NWV-th 32-token tile.  Decode runs 16 waves per workgroup (one per
         // 32 tokens up to 512 of context): a sequence's whole K/V is in flight in one HBM round trip.
         if constexpr (QT == 1) {
-            // decode: two named register sets; the next tile's 16 KiB are in flight while this one is consumed.
-            // Prefetches are unconditional (tile index clamped): no branch around loads.
+            // decode: two named register sets, both in flight; a set is refilled (two tiles ahead) right after it is
+            // consumed.  Prefetches are unconditional (tile index clamped): no branch around loads.
             int kt = t_begin + wave;
-            if (!pre_loaded) load_tile(min(kt, t_end - 1), kaA, kbA, vfA);
-            while (kt < t_end) {
+            if constexpr (FUSED) {
+                const int last = pmax >> 5;  // the tile wave 0 has just written the new token into
+                if (kt < t_end && kt == last) load_tile(kt, kaA, kbA, vfA);
                 load_tile(min(kt + NWV, t_end - 1), kaB, kbB, vfB);
+            } else {
+                load_tile(min(kt, t_end - 1), kaA, kbA, vfA);
+                load_tile(min(kt + NWV, t_end - 1), kaB, kbB, vfB);
+            }
+            while (kt < t_end) {
                 compute_tile(kt, kaA, kbA, vfA);
+                load_tile(min(kt + 2 * NWV, t_end - 1), kaA, kbA, vfA);
                 kt += NWV;
                 if (kt >= t_end) break;
-                load_tile(min(kt + NWV, t_end - 1), kaA, kbA, vfA);
                 compute_tile(kt, kaB, kbB, vfB);
+                load_tile(min(kt + 2 * NWV, t_end - 1), kaB, kbB, vfB);
                 kt += NWV;
             }
         } else {
