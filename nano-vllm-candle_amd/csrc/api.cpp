@@ -914,7 +914,7 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
     }
     if (n_last > 0) {
         // LM head on the last-token rows only (gathered by row_idx), logits scaled by the final norm's rinv
-        GemmPlan pl = plan_gemm(n_last, m->V_l, H, 1);
+        GemmPlan pl = plan_lmhead(n_last, m->V_l, H);
         float* lg = m->want_logits ? m->logits + (size_t)logits_row0 * m->V_l : nullptr;
         rn.row_idx = m->d_last_rows;
         gemm_set_rownorm(&rn);
@@ -1041,7 +1041,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         nf.in = prev; nf.n_slabs = prev_ns; nf.slab_stride = (int64_t)R * H; nf.residual_in = m->resid; nf.row_idx = m->d_last_rows;
         nf.weight = m->norm; nf.eps = eps; nf.H = H; nf.xh = m->xh; nf.xl = m->xl;
         HIPCHK(ctx, launch_add_rmsnorm(nf, n_last, s));
-        GemmPlan pl = plan_gemm(n_last, m->V_l, H, 1);
+        GemmPlan pl = plan_lmhead(n_last, m->V_l, H);
         // logits are stored only when the caller asked for them; the greedy id always comes from the
         // GEMM epilogue's per-wave partial arg-max (LAST max wins), finished by one small kernel
         float* lg = m->want_logits ? m->logits + (size_t)logits_row0 * m->V_l : nullptr;
@@ -1770,7 +1770,7 @@ extern "C" int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int 
     HIPCHK(ctx, launch_synth_rowmajor_bf16(xl, 778, kSynthMatrix, 0, (int64_t)M * K, s));
     // modes 10/11/12: the row-parallel decode kernel with epilogue 0/1/2 (planner shapes; mt/nt/nw/n_split ignored)
     float *resid = nullptr, *nextw = nullptr, *ssq = nullptr, *ssq_in = nullptr;
-    if (mode >= 10) {
+    if (mode >= 10 && mode < 20) {
         if (!gemm_rowpar_ok(N, K, mode - 10, M)) return fail(ctx, NVLLM_EINVAL, "no row-parallel shape for N=%d K=%d epi=%d", N, K, mode - 10);
         HIPCHK(ctx, t.get(&resid, (size_t)M * N)); HIPCHK(ctx, t.get(&nextw, (size_t)N));
         HIPCHK(ctx, t.get(&ssq, (size_t)1024 * 128)); HIPCHK(ctx, t.get(&ssq_in, (size_t)128));
@@ -1778,8 +1778,15 @@ extern "C" int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int 
         HIPCHK(ctx, hipMemsetAsync(ssq_in, 0, 128 * 4, s));
         float* o2; HIPCHK(ctx, t.get(&o2, (size_t)std::max(1, gemm_rowpar_splits(N, K, 2, M)) * M * N)); out = o2;
     }
+    float* pv = nullptr; int* pi = nullptr;
+    GemmPlan plm = plan_lmhead(M, N, K);
+    if (mode == 20 || mode == 21) {  // LM head + arg-max partials: 20 = streaming kernel when applicable, 21 = chunked kernel
+        if (mode == 21) plm = plan_gemm(M, N, K, 1);
+        HIPCHK(ctx, t.get(&pv, (size_t)(N / 16 + 16) * M)); HIPCHK(ctx, t.get(&pi, (size_t)(N / 16 + 16) * M));
+    }
     auto go = [&](int i) -> hipError_t {
         const PackedW& w = ws[i % rot];
+        if (mode == 20 || mode == 21) return launch_gemm_argmax(plm, xh, xl, K, w, nullptr, M, pv, pi, s);
         if (mode >= 10) {
             RowParArgs ra;
             ra.xh = xh; ra.xl = xl; ra.ldx = K; ra.M = M; ra.out = out; ra.resid_in = resid; ra.resid_out = resid; ra.next_w = nextw;

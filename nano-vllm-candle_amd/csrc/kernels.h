@@ -68,8 +68,11 @@ struct GemmPlan {
     int mt, nt, nw, kc;  // m-tiles per WG, n-tiles per wave, waves per WG, k-tiles per LDS chunk
     int n_split;         // K splits across workgroups (slabs)
     int kt_per_split;
+    int lm_nt = 0;       // > 0: launch_gemm_argmax runs the streaming LM-head kernel with lm_nt n-tiles per wave
 };
 GemmPlan plan_gemm(int M, int N, int K, int max_split);  // K % 128 == 0 required
+// LM head (greedy arg-max epilogue): the streaming kernel for <= 64 rows, else plan_gemm(M, N, K, 1)
+GemmPlan plan_lmhead(int M, int N, int K);
 void set_split(GemmPlan& p, int KT, int want);
 hipError_t launch_gemm(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
                        float* out, int M, hipStream_t s);

@@ -49,18 +49,21 @@ __device__ __forceinline__ float rownorm_rinv(const RowNorm& rn, int row) {
 template <int NR>
 __device__ __forceinline__ void rownorm_partials(const RowNorm& rn, int m0, int M, float* lds_part) {
     if (!rn.ssq) return;
-    for (int idx = threadIdx.x; idx < 4 * NR; idx += blockDim.x) {
-        const int r = idx % NR, part = idx / NR;
+    // every thread runs the loads (index clamped, only the LDS store is predicated): loads under a divergent branch
+    // are serialised by the compiler, one vmcnt(0) round trip each
+    for (int i0 = 0; i0 < 4 * NR; i0 += blockDim.x) {
+        const int idx = i0 + (int)threadIdx.x;
+        const int ic = min(idx, 4 * NR - 1);
+        const int r = ic % NR, part = ic / NR;
         int row = min(m0 + r, M - 1);
         if (rn.row_idx) row = rn.row_idx[row];
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = rn.ssq[(size_t)min(part + 4 * i, rn.groups - 1) * rn.stride + row];
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int g = part + 4 * i;
-            const float v = rn.ssq[(size_t)min(g, rn.groups - 1) * rn.stride + row];
-            t += g < rn.groups ? v : 0.f;
-        }
-        lds_part[part * NR + r] = t;
+        for (int i = 0; i < 16; ++i) t += (part + 4 * i) < rn.groups ? v[i] : 0.f;
+        if (idx < 4 * NR) lds_part[part * NR + r] = t;
     }
 }
 template <int NR>
@@ -558,12 +561,203 @@ hipError_t launch_gemm(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* 
     return gemm_dispatch<0>(p, xh, xl, ldx, w, out, M, GemmExtra{}, s);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LM head for decode (<= 64 rows): logits = x.W^T (Qwen3ForCausalLM::compute_logits, qwen3.rs:542-550) with
+// the greedy arg-max (llm_engine.rs:135-142, LAST max wins) in the epilogue.  The vocabulary matrix is the
+// largest stream of a step (311 MB for Qwen3-0.6B), read exactly once: one workgroup per CU, 8 waves, each wave
+// owns NT n-tiles for the WHOLE K and keeps two 2-k-tile weight sets (2*NT KiB each) in flight while all 64 rows
+// of x ride through LDS in 8-k-tile chunks (double buffered, every wave stages one k-tile of a chunk).
+// ---------------------------------------------------------------------------------------------------
+template <int MT, int NT, int NCH>
+__global__ void __launch_bounds__(512) lmhead_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, int ldx,
+                                                     const uint4* __restrict__ wp, float* __restrict__ out, int M, int N, int KT,
+                                                     float* __restrict__ part_val, int* __restrict__ part_idx, RowNorm rn) {
+    constexpr int NW = 8, KC = 8, SC = MT == 4 ? 1 : 2;  // 64 rows: 80 accumulator registers leave room for 1-k-tile sets only
+    constexpr int FRAGS = 2 * MT * KC;  // 1 KiB fragments per x chunk: [2 planes][MT][KC]
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint4* lds = reinterpret_cast<uint4*>(smem_raw);                                    // [2][FRAGS][64]
+    float* lds_rn = reinterpret_cast<float*>(smem_raw + (size_t)2 * FRAGS * 1024);      // [4][MT*16]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int ntiles = N >> 4;
+    const int nt0 = ((int)blockIdx.x * NW + wave) * NT;
+    // deferred-norm partials first, while no other registers are live: 16 independent loads, parked in LDS
+    rownorm_partials<MT * 16>(rn, 0, M, lds_rn);
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned xoff[MT];  // element offset of this lane's 16-byte piece in row block b (k-tile 0), < 2^32 elements
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+        int r = min(b * 16 + l15, M - 1);
+        if (rn.row_idx) r = rn.row_idx[r];
+        xoff[b] = (unsigned)r * (unsigned)ldx + (unsigned)(wave * 32 + grp * 8);
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // wave w stages k-tile w of the chunk for both planes and every row block (2*MT LDS-DMA loads)
+    auto stage = [&](int c, int buf) {
+#pragma unroll
+        for (int plane = 0; plane < 2; ++plane)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const uint16_t* src = (plane ? xl : xh) + (size_t)(xoff[b] + (unsigned)(c * KC * 32));
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (size_t)(buf * FRAGS + (plane * MT + b) * KC + wave) * 64), 16, 0, 0);
+            }
+    };
+    uint4 wA[NT][SC], wB[NT][SC];
+    auto issue_w = [&](int kt0, uint4 (&w)[NT][SC]) {
+        const int kt = min(kt0, KT - SC);  // past the end: a harmless re-read of the last set
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int ntc = min(nt0 + a, ntiles - 1);
+#pragma unroll
+            for (int j = 0; j < SC; ++j) w[a][j] = wp[((size_t)ntc * KT + kt + j) * 64 + lane];
+        }
+    };
+    auto compute = [&](int k0, int buf, const uint4 (&w)[NT][SC]) {
+#pragma unroll
+        for (int j = 0; j < SC; ++j)
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane) {  // hi plane, then lo plane: MT x-fragments live at a time
+                bf16x8 bx[MT];
+#pragma unroll
+                for (int b = 0; b < MT; ++b)
+                    bx[b] = __builtin_bit_cast(bf16x8, lds[(size_t)(buf * FRAGS + (plane * MT + b) * KC + k0 + j) * 64 + lane]);
+#pragma unroll
+                for (int a = 0; a < NT; ++a) {
+                    const bf16x8 wv = __builtin_bit_cast(bf16x8, w[a][j]);
+#pragma unroll
+                    for (int b = 0; b < MT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, bx[b], acc[a][b], 0, 0, 0);
+                }
+            }
+    };
+    // NCH > 0: the chunk loop is fully unrolled (the compiler then tracks every load in flight exactly; with a
+    // back-edge it falls back to vmcnt(0) after each refill)
+    const int nchunks = NCH > 0 ? NCH : KT / KC;
+    stage(0, 0);
+    issue_w(0, wA);
+    issue_w(SC, wB);
+#pragma unroll
+    for (int c = 0; c < nchunks; ++c) {
+        // chunk c is in LDS and every wave is done with the other buffer.  After the first chunk the wait covers
+        // only this wave's x stage: the KC/SC weight sets issued after it (vmcnt retires in order) stay in flight
+        // across the barrier instead of draining the stream four times per launch.
+        if (c == 0) __syncthreads();
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((KC / SC) * NT * SC) : "memory");
+        if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);  // the weight loads below are issued AFTER the stage (the count above relies on it)
+        const int base = c * KC, buf = c & 1;
+        // scheduling fences: a refill is issued exactly where it is written (the compiler otherwise sinks it to its
+        // first use to save registers, which serialises every 1 KiB load behind a vmcnt(0))
+#define NVLLM_LM_STEP(k0_, set_, next_)            \
+    compute(k0_, buf, set_);                       \
+    __builtin_amdgcn_sched_barrier(0);             \
+    issue_w(next_, set_);                          \
+    __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SC == 2) {
+            NVLLM_LM_STEP(0, wA, base + 4)
+            NVLLM_LM_STEP(2, wB, base + 6)
+            NVLLM_LM_STEP(4, wA, base + 8)
+            NVLLM_LM_STEP(6, wB, base + 10)
+        } else {
+            NVLLM_LM_STEP(0, wA, base + 2)
+            NVLLM_LM_STEP(1, wB, base + 3)
+            NVLLM_LM_STEP(2, wA, base + 4)
+            NVLLM_LM_STEP(3, wB, base + 5)
+            NVLLM_LM_STEP(4, wA, base + 6)
+            NVLLM_LM_STEP(5, wB, base + 7)
+            NVLLM_LM_STEP(6, wA, base + 8)
+            NVLLM_LM_STEP(7, wB, base + 9)
+        }
+#undef NVLLM_LM_STEP
+    }
+    if (rn.ssq) {  // deferred final norm: logits = rinv[row] * acc
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+            const float ri = rownorm_rinv_lds<MT * 16>(rn, lds_rn, b * 16 + l15);
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                acc[a][b][0] *= ri; acc[a][b][1] *= ri; acc[a][b][2] *= ri; acc[a][b][3] *= ri;
+            }
+        }
+    }
+    const int wg = (int)blockIdx.x * NW + wave;
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+        const int row = b * 16 + l15;
+        float bv = -INFINITY;
+        int bi = -1;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            if (nt0 + a >= ntiles) continue;
+            const f32x4 v = acc[a][b];
+            if (out && row < M) *reinterpret_cast<float4*>(out + (size_t)row * N + (size_t)(nt0 + a) * 16 + grp * 4) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int idx = (nt0 + a) * 16 + grp * 4 + r;
+                if (bi < 0 || v[r] > bv || (v[r] == bv && idx > bi)) { bv = v[r]; bi = idx; }
+            }
+        }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
+        }
+        if (grp == 0 && row < M) {
+            part_val[(size_t)wg * M + row] = bv;
+            part_idx[(size_t)wg * M + row] = bi;
+        }
+    }
+}
+
+template <int MT, int NT, int NCH>
+static hipError_t lmhead_launch_t(const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w, float* out, int M,
+                                  float* part_val, int* part_idx, const RowNorm& rn, hipStream_t s) {
+    const size_t lds = (size_t)2 * (2 * MT * 8) * 1024 + (size_t)4 * MT * 16 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lmhead_kernel<MT, NT, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int waves = (w.N / 16 + NT - 1) / NT;
+    lmhead_kernel<MT, NT, NCH><<<(waves + 7) / 8, 512, lds, s>>>(xh, xl, ldx, w.data, out, M, w.N, w.K / 32, part_val, part_idx, rn);
+    return hipGetLastError();
+}
+
+GemmPlan plan_lmhead(int M, int N, int K) {
+    GemmPlan p = plan_gemm(M, N, K, 1);
+    static const bool off = getenv("NVLLM_NO_LMHEAD") != nullptr;
+    if (off || M > 64 || K % 256 || N % 16) return p;
+    // one workgroup (8 waves) per CU: n-tiles per wave so that the grid fits the 256 CUs in one round
+    const int ntiles = N / 16;
+    int nt = (ntiles + 2047) / 2048;
+    if (nt > 6) nt = 6;  // bigger vocabularies run several rounds
+    p.lm_nt = nt;
+    return p;
+}
+
 hipError_t launch_gemm_argmax(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
                               float* out, int M, float* part_val, int* part_idx, hipStream_t s) {
     if (!part_val || !part_idx || p.n_split != 1) return hipErrorInvalidValue;
     GemmExtra x;
     x.part_val = part_val; x.part_idx = part_idx;
     x.rn = g_next_rownorm; g_next_rownorm = RowNorm{};
+    if (p.lm_nt > 0) {
+        if (M < 1 || M > 64 || w.K % 256) return hipErrorInvalidValue;
+        const int mt = M <= 16 ? 1 : M <= 32 ? 2 : 4;
+#define NVLLM_LM(MT_, NT_)                                                                                                   \
+    if (mt == MT_ && p.lm_nt == NT_)                                                                                       \
+        return w.K == 1024 ? lmhead_launch_t<MT_, NT_, 4>(xh, xl, ldx, w, out, M, part_val, part_idx, x.rn, s)             \
+                           : lmhead_launch_t<MT_, NT_, 0>(xh, xl, ldx, w, out, M, part_val, part_idx, x.rn, s);
+#define NVLLM_LM_MT(MT_) NVLLM_LM(MT_, 1) NVLLM_LM(MT_, 2) NVLLM_LM(MT_, 3) NVLLM_LM(MT_, 4) NVLLM_LM(MT_, 5) NVLLM_LM(MT_, 6)
+        NVLLM_LM_MT(1) NVLLM_LM_MT(2) NVLLM_LM_MT(4)
+#undef NVLLM_LM_MT
+#undef NVLLM_LM
+        return hipErrorNotSupported;
+    }
     return gemm_dispatch<1>(p, xh, xl, ldx, w, out, M, x, s);
 }
 
@@ -592,7 +786,10 @@ GemmPlan plan_gemm_swiglu(int M, int N2, int K) {
     return p;
 }
 
-int gemm_argmax_parts(const GemmPlan& p, int N) { return ((N / 16 + p.nt * p.nw - 1) / (p.nt * p.nw)) * p.nw; }
+int gemm_argmax_parts(const GemmPlan& p, int N) {
+    if (p.lm_nt > 0) return (((N / 16 + p.lm_nt - 1) / p.lm_nt + 7) / 8) * 8;  // one partial per wave, 8 waves per workgroup
+    return ((N / 16 + p.nt * p.nw - 1) / (p.nt * p.nw)) * p.nw;
+}
 
 hipError_t launch_argmax_parts(const float* part_val, const int* part_idx, int n_parts, int M, void* scratch,
                                uint32_t* ids, float* maxval, hipStream_t s) {
@@ -1315,7 +1512,8 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
         const int rank = ((lin >> 8) & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
         tile = a.tile_order[rank];
     }
-    const int row0 = a.tile_row0[tile], nrows = a.tile_nrows[tile], slot = a.tile_slot[tile];
+    // fused decode: every q-tile is one row and tile i is row i (no tile_row0/tile_nrows round trip)
+    const int row0 = FUSED ? tile : a.tile_row0[tile], nrows = FUSED ? 1 : a.tile_nrows[tile], slot = a.tile_slot[tile];
     const int gqa = a.gqa, tpq = 16 / gqa;
     const int kv_l = a.kv.kv_l;
     const int ldq = a.nh_l * HD;
@@ -1714,7 +1912,7 @@ hipError_t launch_attn_paged(const AttnArgs& a, int n_tiles, int qt, int rows, i
     const int gz = split ? n_parts_max : 1;
     hipError_t e = hipErrorInvalidValue;
     const bool fused = a.qkv != nullptr;  // decode rows straight from the QKV GEMM's slabs
-    if (fused && qt != 1) return hipErrorInvalidValue;
+    if (fused && (qt != 1 || n_tiles != rows)) return hipErrorInvalidValue;  // fused decode: tile i is row i
     static const int decode_waves = [] { const char* e = getenv("NVLLM_ATTN_WAVES"); return e ? atoi(e) : 4; }();
     if (a.kv.hd == 128 && qt == 1 && decode_waves == 8) e = fused ? attn_launch_t<128, 1, 8, true>(b, n_tiles, gz, s) : attn_launch_t<128, 1, 8, false>(b, n_tiles, gz, s);
     else if (a.kv.hd == 128 && qt == 1) e = fused ? attn_launch_t<128, 1, 4, true>(b, n_tiles, gz, s) : attn_launch_t<128, 1, 4, false>(b, n_tiles, gz, s);
