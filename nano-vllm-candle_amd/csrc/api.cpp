@@ -919,8 +919,11 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
         rn.row_idx = m->d_last_rows;
         gemm_set_rownorm(&rn);
         PROF(m, PROF_LMHEAD, launch_gemm_argmax(pl, m->xh, m->xl, H, m->lm_head, lg, n_last, m->part_val, m->part_idx, s));
-        HIPCHK(ctx, launch_argmax_parts(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, m->argmax_scratch,
-                                        m->d_next + logits_row0, nullptr, s));
+        if (pl.lm_nt > 0)
+            HIPCHK(ctx, launch_argmax_rows(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, m->d_next + logits_row0, nullptr, s));
+        else
+            HIPCHK(ctx, launch_argmax_parts(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, m->argmax_scratch,
+                                            m->d_next + logits_row0, nullptr, s));
     }
     return NVLLM_OK;
 }
@@ -1049,7 +1052,10 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         const int tp = ctx->tp_size;
         uint32_t* ids_dst = tp == 1 ? m->d_next + logits_row0 : m->d_next + m->cur_n + (size_t)ctx->tp_rank * m->cur_n + logits_row0;
         float* val_dst = tp == 1 ? nullptr : m->d_maxval + (size_t)ctx->tp_rank * m->cur_n + logits_row0;
-        HIPCHK(ctx, launch_argmax_parts(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, m->argmax_scratch, ids_dst, val_dst, s));
+        if (pl.lm_nt > 0)
+            HIPCHK(ctx, launch_argmax_rows(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, ids_dst, val_dst, s));
+        else
+            HIPCHK(ctx, launch_argmax_parts(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, m->argmax_scratch, ids_dst, val_dst, s));
     }
     return NVLLM_OK;
 }

@@ -87,6 +87,8 @@ GemmPlan plan_gemm_swiglu(int M, int N2, int K);
 hipError_t launch_gemm_swiglu(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
                               int M, bf16_bits* act_hi, bf16_bits* act_lo, hipStream_t s);
 // scratch: 8*(M+1) bytes, zero before the first use (the kernel leaves it zero again)
+// finish of the streaming LM head (plan.lm_nt > 0): partials are [row][n_parts], one workgroup per row
+hipError_t launch_argmax_rows(const float* part_val, const int* part_idx, int n_parts, int M, uint32_t* ids, float* maxval, hipStream_t s);
 hipError_t launch_argmax_parts(const float* part_val, const int* part_idx, int n_parts, int M, void* scratch,
                                uint32_t* ids, float* maxval, hipStream_t s);
 

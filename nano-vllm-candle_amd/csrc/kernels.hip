@@ -706,11 +706,58 @@ __global__ void __launch_bounds__(512) lmhead_kernel(const uint16_t* __restrict_
             const int oi = __shfl_xor(bi, o);
             if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
         }
-        if (grp == 0 && row < M) {
-            part_val[(size_t)wg * M + row] = bv;
-            part_idx[(size_t)wg * M + row] = bi;
+        if (grp == 0 && row < M) {  // part_*[row][wave]: one workgroup per row finishes (argmax_rows_kernel)
+            const size_t n_parts = (size_t)gridDim.x * NW;
+            part_val[(size_t)row * n_parts + wg] = bv;
+            part_idx[(size_t)row * n_parts + wg] = bi;
         }
     }
+}
+
+// finish the streaming LM head's arg-max: part_*[row][n_parts], one workgroup per row, no atomics
+__global__ void __launch_bounds__(256) argmax_rows_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx,
+                                                          int n_parts, uint32_t* __restrict__ ids, float* __restrict__ maxval) {
+    __shared__ unsigned long long sk[4];
+    const int row = blockIdx.x;
+    const float* pv = part_val + (size_t)row * n_parts;
+    const int* pi = part_idx + (size_t)row * n_parts;
+    unsigned long long best = 0;
+    for (int p0 = 0; p0 < n_parts; p0 += 256 * 4) {
+        int i4[4]; float v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // unconditional loads (clamped), validity applied afterwards
+            const int p = min(p0 + u * 256 + (int)threadIdx.x, n_parts - 1);
+            i4[u] = pi[p]; v4[u] = pv[p];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = (p0 + u * 256 + (int)threadIdx.x) < n_parts && i4[u] >= 0;
+            const unsigned long long k = ok ? argmax_key(v4[u], i4[u]) : 0ull;
+            best = k > best ? k : best;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned lo = __shfl_xor((unsigned)best, o), hi = __shfl_xor((unsigned)(best >> 32), o);
+        const unsigned long long k = ((unsigned long long)hi << 32) | lo;
+        best = k > best ? k : best;
+    }
+    if ((threadIdx.x & 63) == 0) sk[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 4; ++q) best = sk[q] > best ? sk[q] : best;
+        ids[row] = (uint32_t)(best & 0xffffffffu);
+        if (maxval) {
+            unsigned u = (unsigned)(best >> 32);
+            u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+            maxval[row] = __builtin_bit_cast(float, u);
+        }
+    }
+}
+hipError_t launch_argmax_rows(const float* part_val, const int* part_idx, int n_parts, int M, uint32_t* ids, float* maxval, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    argmax_rows_kernel<<<M, 256, 0, s>>>(part_val, part_idx, n_parts, ids, maxval);
+    return hipGetLastError();
 }
 
 template <int MT, int NT, int NCH>
