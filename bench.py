@@ -238,7 +238,7 @@ def main():
     kern = {}
     pass_steps = max(1, a.profile_steps // 4)
     attn_ctx = []
-    for kind in ("attn", "gemm", "lm_head", "norm", "qk", "silu"):
+    for kind in ("attn", "gemm", "lm_head", "norm", "qk", "silu", "empty"):
         model.profile_kernel(kind)
         for _ in range(pass_steps):
             if kind == "attn":
@@ -247,6 +247,9 @@ def main():
             ctx_lens += 1
         kern[kind] = model.profile_read()
     model.profile_kernel(None)
+    # an event pair around nothing, recorded between busy kernels: what every bracket adds to a launch's duration
+    empty_ms, empty_n = kern.pop("empty")
+    bracket_us = empty_ms / max(empty_n, 1) * 1e3
     per_step = {k: ms / pass_steps for k, (ms, n) in kern.items()}
     kv_layer = model.kv_bytes_per_token // cfg.num_hidden_layers  # K+V bytes of one token in one layer (this rank)
     # dominant kernel = the class that moves the most algorithmic bytes per step (the path is HBM-bound); the
@@ -270,8 +273,10 @@ def main():
         dom_bytes = None
         dom_name = dom
     step_gbs = (bytes_total / a.steps) / (ev_ms / a.steps * 1e-3) / 1e9
+    raw_us = dom_ms / max(dom_n, 1) * 1e3
+    launch_us = max(raw_us - bracket_us, 1e-3)  # bracketed duration minus the calibrated empty bracket
     roof = {"bound": "hbm", "kernel": dom_name, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-            "avg_launch_us": dom_ms / max(dom_n, 1) * 1e3}
+            "avg_launch_us": launch_us, "avg_launch_us_bracketed": raw_us, "empty_bracket_us": bracket_us}
     # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, gfx950 x2 correction applied):
     # a separate profiled run of this same command, so it is quoted with that run's own algorithmic bytes
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")
@@ -281,7 +286,7 @@ def main():
             roof["traffic"] = pmc["fetch_bytes_per_launch"]
             roof["traffic_run_algorithmic_bytes"] = pmc["algorithmic_bytes_per_launch"]
     if dom_bytes is not None:
-        roof["achieved"] = dom_bytes / (dom_ms / max(dom_n, 1) * 1e-3) / 1e9
+        roof["achieved"] = dom_bytes / (launch_us * 1e-6) / 1e9
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
         roof["bytes_per_launch"] = dom_bytes
     out = {

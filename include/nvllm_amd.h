@@ -142,7 +142,9 @@ int nvllm_decode_collect(nvllm_model* m, uint32_t* next_ids);
  * weight_bytes + sum_seq ctx*kv_tok + n_seqs*kv_tok (+ 4*n_seqs*vocab when logits left the device) */
 int64_t nvllm_last_step_bytes(const nvllm_model* m);
 /* HIP-event timing of one kernel class on the library stream (bench.py's roofline leg):
- * kind 0 off, 1 paged attention, 2 layer GEMMs, 3 add+RMSNorm, 4 qk-norm/RoPE/KV-write, 5 SwiGLU, 6 LM head.
+ * kind 0 off, 1 paged attention, 2 layer GEMMs, 3 add+RMSNorm, 4 qk-norm/RoPE/KV-write, 5 SwiGLU, 6 LM head,
+ * 7 calibration (an event pair around NO launch, recorded where the decode attention launch sits: the elapsed
+ * time of an empty bracket between busy kernels, to be subtracted from the bracketed durations).
  * While a kind is set every launch of that class is bracketed by two events; read returns the summed
  * elapsed ms and the number of launches since the last read. */
 int nvllm_profile_kernel(nvllm_model* m, int kind);

@@ -249,7 +249,7 @@ class Qwen3ForCausalLM:
         _lib.check(_lib.lib().nvllm_decode_collect(self.h, buf.ctypes.data_as(C.POINTER(C.c_uint32))), self.ctx.h)
         return buf
 
-    PROF_KINDS = {"attn": 1, "gemm": 2, "norm": 3, "qk": 4, "silu": 5, "lm_head": 6}
+    PROF_KINDS = {"attn": 1, "gemm": 2, "norm": 3, "qk": 4, "silu": 5, "lm_head": 6, "empty": 7}
 
     def profile_kernel(self, kind):
         """HIP-event bracketing of one kernel class on the library stream (None/0 = off)"""
