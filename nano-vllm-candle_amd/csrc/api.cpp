@@ -931,9 +931,19 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
 
 // y (f32 slabs) = x.W^T on the generic path: for few rows the row-parallel streaming kernel (every load of a
 // workgroup issued up front) beats the chunked kernel on big matrices; otherwise the chunked kernel.
+static bool gemm_streams(const nvllm_model* m, const PackedW& w, int R) {
+    const int ss = gemm_stream_splits(R, w.N, w.K);
+    return ss > 0 && (size_t)ss * R * w.N <= m->slab_floats;
+}
 static int gemm_slabs(nvllm_model* m, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w, float* out, int R,
-                      int max_split, int* n_slabs) {
+                      int max_split, int* n_slabs, int x_packed = 0) {
     nvllm_ctx* ctx = m->ctx;
+    if (gemm_streams(m, w, R)) {
+        PROF(m, PROF_GEMM, launch_gemm_stream(xh, xl, ldx, w, out, R, x_packed, ctx->stream));
+        *n_slabs = gemm_stream_splits(R, w.N, w.K);
+        return NVLLM_OK;
+    }
+    if (x_packed) return fail(ctx, NVLLM_ESTATE, "packed activation planes reached a non-streaming GEMM");
     if (R <= kFusedMaxRows && gemm_rowpar_ok(w.N, w.K, 2, R) &&
         (size_t)gemm_rowpar_splits(w.N, w.K, 2, R) * R * w.N <= m->slab_floats && !getenv("NVLLM_NO_ROWPAR")) {
         RowParArgs ra;
@@ -960,10 +970,15 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
     const float* prev = nullptr;  // output of the previous layer's MLP (slabs or reduced)
     int prev_ns = 1;
     m->tap_rows = R;
+    // big-model decode: when all four projections of a layer run the streaming GEMM, the activation planes between
+    // the row kernels and the GEMMs stay in MFMA fragment order (xpack_off): x staging costs 3x per byte otherwise
+    static const bool no_xpack = getenv("NVLLM_NO_XPACK") != nullptr;
+    const int packed = !no_xpack && !m->layers.empty() && gemm_streams(m, m->layers[0].qkv, R) && gemm_streams(m, m->layers[0].o, R) &&
+                       gemm_streams(m, m->layers[0].gu, R) && gemm_streams(m, m->layers[0].down, R) && m->I_l % 32 == 0;
     for (int l = 0; l < m->L; ++l) {
         const LayerW& w = m->layers[l];
         NormArgs na;
-        na.weight = w.ln1; na.eps = eps; na.H = H; na.xh = m->xh; na.xl = m->xl; na.residual_out = m->resid;
+        na.weight = w.ln1; na.eps = eps; na.H = H; na.xh = m->xh; na.xl = m->xl; na.residual_out = m->resid; na.out_packed = packed;
         if (l == 0) {  // residual None: normed = norm(x), residual = x  (qwen3.rs:382-386)
             na.ids = m->d_ids; na.embed = m->embed;
         } else {       // qwen3.rs:378
@@ -972,7 +987,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         PROF(m, PROF_NORM, launch_add_rmsnorm(na, R, s));
         // QKV projection (qwen3.rs:205)
         QkvArgs qa;
-        int rcg = gemm_slabs(m, m->xh, m->xl, H, w.qkv, m->slabs, R, 8, &qa.n_slabs);
+        int rcg = gemm_slabs(m, m->xh, m->xl, H, w.qkv, m->slabs, R, 8, &qa.n_slabs, packed);
         if (rcg) return rcg;
         qa.qkv = m->slabs; qa.slab_stride = (int64_t)R * NQ; qa.qn = w.qn; qa.kn = w.kn; qa.eps = eps;
         qa.cos = m->cosv; qa.sin = m->sinv; qa.pos = m->d_pos; qa.slot = m->d_slot; qa.block_tables = m->d_block_tables;
@@ -985,7 +1000,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         AttnArgs aa;
         aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
         aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
-        aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->xh; aa.out_lo = m->xl;
+        aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->xh; aa.out_lo = m->xl; aa.out_packed = packed;
         if (qt == 1) aa.tile_order = m->d_tile_order;
         if (fuse_qk) {
             aa.qkv = qa.qkv; aa.n_slabs = qa.n_slabs; aa.slab_stride = qa.slab_stride; aa.ldqkv = NQ; aa.qn = w.qn; aa.kn = w.kn;
@@ -1000,36 +1015,36 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         // output projection (qwen3.rs:278) + TP all-reduce
         const int KO = m->nh_l * hd;
         int o_slabs = 1;
-        rcg = gemm_slabs(m, m->xh, m->xl, KO, w.o, m->slabs, R, 8, &o_slabs);
+        rcg = gemm_slabs(m, m->xh, m->xl, KO, w.o, m->slabs, R, 8, &o_slabs, packed);
         if (rcg) return rcg;
         const float* oin; int ons;
         int rc = tp_reduce(m, R, o_slabs, &oin, &ons);
         if (rc) return rc;
         NormArgs nb;  // post-attention add + norm (qwen3.rs:393)
         nb.in = oin; nb.n_slabs = ons; nb.slab_stride = (int64_t)R * H; nb.residual_in = m->resid; nb.residual_out = m->resid;
-        nb.weight = w.ln2; nb.eps = eps; nb.H = H; nb.xh = m->xh; nb.xl = m->xl;
+        nb.weight = w.ln2; nb.eps = eps; nb.H = H; nb.xh = m->xh; nb.xl = m->xl; nb.out_packed = packed;
         PROF(m, PROF_NORM, launch_add_rmsnorm(nb, R, s));
         // MLP (qwen3.rs:323-327)
-        if (R <= kFusedMaxRows && gemm_rowpar_ok(2 * m->I_l, H, 1, R)) {
+        if (!packed && R <= kFusedMaxRows && gemm_rowpar_ok(2 * m->I_l, H, 1, R)) {
             // small gate/up: whole-K row-parallel kernel with the SiLU*mul epilogue
             RowParArgs rg;
             rg.xh = m->xh; rg.xl = m->xl; rg.ldx = H; rg.oh = m->xh2; rg.ol = m->xl2; rg.M = R;
             PROF(m, PROF_GEMM, launch_gemm_rowpar(rg, w.gu, 1, s));
-        } else if (R <= kFusedMaxRows && gemm_rowpar_ok(2 * m->I_l, H, 2, R) &&
-                   (size_t)gemm_rowpar_splits(2 * m->I_l, H, 2, R) * R * 2 * m->I_l <= m->slab_floats && !getenv("NVLLM_NO_ROWPAR")) {
+        } else if (packed || (R <= kFusedMaxRows && gemm_rowpar_ok(2 * m->I_l, H, 2, R) &&
+                              (size_t)gemm_rowpar_splits(2 * m->I_l, H, 2, R) * R * 2 * m->I_l <= m->slab_floats && !getenv("NVLLM_NO_ROWPAR"))) {
             // big gate/up at few rows: stream it with K slices (f32 slabs of the INTERLEAVED gate/up rows),
             // then SiLU*mul on the summed slabs
             int gs = 1;
-            rcg = gemm_slabs(m, m->xh, m->xl, H, w.gu, m->slabs, R, 8, &gs);
+            rcg = gemm_slabs(m, m->xh, m->xl, H, w.gu, m->slabs, R, 8, &gs, packed);
             if (rcg) return rcg;
-            PROF(m, PROF_SILU, launch_silu_mul_interleaved(m->slabs, gs, (int64_t)R * 2 * m->I_l, R, m->I_l, m->xh2, m->xl2, s));
+            PROF(m, PROF_SILU, launch_silu_mul_interleaved(m->slabs, gs, (int64_t)R * 2 * m->I_l, R, m->I_l, m->xh2, m->xl2, packed, s));
         } else {
             // gate/up GEMM with the SiLU*mul epilogue: act hi/lo written directly, no slabs, no extra launch
             GemmPlan pg = plan_gemm_swiglu(R, 2 * m->I_l, H);
             PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, s));
         }
         int d_slabs = 1;
-        rcg = gemm_slabs(m, m->xh2, m->xl2, m->I_l, w.down, m->slabs, R, 8, &d_slabs);
+        rcg = gemm_slabs(m, m->xh2, m->xl2, m->I_l, w.down, m->slabs, R, 8, &d_slabs, packed);
         if (rcg) return rcg;
         rc = tp_reduce(m, R, d_slabs, &prev, &prev_ns);
         if (rc) return rc;
@@ -1777,6 +1792,10 @@ extern "C" int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int 
     HIPCHK(ctx, launch_synth_rowmajor_bf16(xl, 778, kSynthMatrix, 0, (int64_t)M * K, s));
     // modes 10/11/12: the row-parallel decode kernel with epilogue 0/1/2 (planner shapes; mt/nt/nw/n_split ignored)
     float *resid = nullptr, *nextw = nullptr, *ssq = nullptr, *ssq_in = nullptr;
+    if (mode == 22 || mode == 23) {
+        if (!gemm_stream_splits(M, N, K)) return fail(ctx, NVLLM_EINVAL, "no streaming shape for M=%d N=%d K=%d", M, N, K);
+        float* o2; HIPCHK(ctx, t.get(&o2, (size_t)gemm_stream_splits(M, N, K) * M * N)); out = o2;
+    }
     if (mode >= 10 && mode < 20) {
         if (!gemm_rowpar_ok(N, K, mode - 10, M)) return fail(ctx, NVLLM_EINVAL, "no row-parallel shape for N=%d K=%d epi=%d", N, K, mode - 10);
         HIPCHK(ctx, t.get(&resid, (size_t)M * N)); HIPCHK(ctx, t.get(&nextw, (size_t)N));
@@ -1794,6 +1813,7 @@ extern "C" int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int 
     auto go = [&](int i) -> hipError_t {
         const PackedW& w = ws[i % rot];
         if (mode == 20 || mode == 21) return launch_gemm_argmax(plm, xh, xl, K, w, nullptr, M, pv, pi, s);
+        if (mode == 22 || mode == 23) return launch_gemm_stream(xh, xl, K, w, out, M, mode == 23, s);  // 23: packed x planes
         if (mode >= 10) {
             RowParArgs ra;
             ra.xh = xh; ra.xl = xl; ra.ldx = K; ra.M = M; ra.out = out; ra.resid_in = resid; ra.resid_out = resid; ra.next_w = nextw;

@@ -71,6 +71,12 @@ struct GemmPlan {
     int lm_nt = 0;       // > 0: launch_gemm_argmax runs the streaming LM-head kernel with lm_nt n-tiles per wave
 };
 GemmPlan plan_gemm(int M, int N, int K, int max_split);  // K % 128 == 0 required
+// streaming GEMM for big decode matrices (>= 24 MB, 17..64 rows): f32 slabs out[gemm_stream_splits][M][N];
+// gemm_stream_splits == 0 -> shape not covered (use launch_gemm / launch_gemm_rowpar)
+int gemm_stream_splits(int M, int N, int K);
+// x_packed: the planes are in xpack_off order (ldx = K either way)
+hipError_t launch_gemm_stream(const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w, float* out, int M, int x_packed,
+                              hipStream_t s);
 // LM head (greedy arg-max epilogue): the streaming kernel for <= 64 rows, else plan_gemm(M, N, K, 1)
 GemmPlan plan_lmhead(int M, int N, int K);
 void set_split(GemmPlan& p, int KT, int want);
@@ -216,8 +222,9 @@ hipError_t launch_silu_mul(const float* gu, int n_slabs, int64_t slab_stride, in
                            bf16_bits* lo, float* y, hipStream_t s);
 
 // gu in the packed weight's interleaved 16-row-tile order (gate tile, up tile, ...) -> act hi/lo [rows][I]
+// out_packed: hi/lo in xpack_off order (the streaming GEMM's input)
 hipError_t launch_silu_mul_interleaved(const float* gu, int n_slabs, int64_t slab_stride, int rows, int I, bf16_bits* hi,
-                                       bf16_bits* lo, hipStream_t s);
+                                       bf16_bits* lo, int out_packed, hipStream_t s);
 
 // ---- misc --------------------------------------------------------------------------------------------
 // y[r][:] = sum_s in[s][r][:] (+ bias)  -- finishes a split-K GEMM for the fine-seam op

@@ -774,6 +774,164 @@ static hipError_t lmhead_launch_t(const bf16_bits* xh, const bf16_bits* xl, int 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Streaming GEMM for the big decode matrices (>= 24 MB, 17..64 rows: Qwen3-8B/32B layers, TP shards): the
+// lmhead_kernel pipeline with the K range cut into slices over blockIdx.y so that about one workgroup of 8 waves
+// lands on every CU.  A wave owns NT n-tiles over its slice and keeps two SC-k-tile weight sets in flight
+// (NT*SC = 4..6 KiB each); x rides through LDS in 8-k-tile chunks; slice ks leaves the f32 slab out[ks][M][N]
+// (summed by the consumer: add_rmsnorm / silu_mul / attention prologue).  Replaces the phase-stepped
+// gemm_rowpar_kernel<4,8,1,8,PH,2> (2.2-2.7 TB/s on the 8B shapes: four dependent 8 KiB phases per wave).
+// ---------------------------------------------------------------------------------------------------
+template <int NT, int SC>
+__global__ void __launch_bounds__(512) gemm_stream_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, int ldx,
+                                                          const uint4* __restrict__ wp, float* __restrict__ out, int M, int N, int KT,
+                                                          int kts, int x_packed) {
+    constexpr int MT = 4, NW = 8, KC = 8;
+    constexpr int FRAGS = 2 * MT * KC;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint4* lds = reinterpret_cast<uint4*>(smem_raw);  // [2][FRAGS][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int ntiles = N >> 4;
+    const int nt0 = ((int)blockIdx.x * NW + wave) * NT;
+    const int kt_begin = (int)blockIdx.y * kts;
+    // element offset of this lane's 16 bytes of k-tile (kt_begin + wave), row block b; xstep = one k-tile further.
+    // Row-major planes: 16 rows x 64 B per fragment; packed planes (xpack_off order): one contiguous 1 KiB fragment
+    unsigned xoff[MT];
+    const unsigned xstep = x_packed ? 512u : 32u;
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+        xoff[b] = x_packed ? (unsigned)((b * (ldx >> 5) + kt_begin + wave) * 512 + lane * 8)
+                           : (unsigned)min(b * 16 + l15, M - 1) * (unsigned)ldx + (unsigned)((kt_begin + wave) * 32 + grp * 8);
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](int c, int buf) {
+#pragma unroll
+        for (int plane = 0; plane < 2; ++plane)
+#pragma unroll
+            for (int b = 0; b < MT; ++b) {
+                const uint16_t* src = (plane ? xl : xh) + (size_t)(xoff[b] + (unsigned)(c * KC) * xstep);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (size_t)(buf * FRAGS + (plane * MT + b) * KC + wave) * 64), 16, 0, 0);
+            }
+    };
+    uint4 wA[NT][SC], wB[NT][SC];
+    auto issue_w = [&](int k_rel, uint4 (&w)[NT][SC]) {
+        const int kt = kt_begin + min(k_rel, kts - SC);  // past the slice: a harmless re-read of its last set
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int ntc = min(nt0 + a, ntiles - 1);
+#pragma unroll
+            for (int j = 0; j < SC; ++j) w[a][j] = wp[((size_t)ntc * KT + kt + j) * 64 + lane];
+        }
+    };
+    auto compute = [&](int k0, int buf, const uint4 (&w)[NT][SC]) {
+#pragma unroll
+        for (int j = 0; j < SC; ++j)
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane) {
+                bf16x8 bx[MT];
+#pragma unroll
+                for (int b = 0; b < MT; ++b)
+                    bx[b] = __builtin_bit_cast(bf16x8, lds[(size_t)(buf * FRAGS + (plane * MT + b) * KC + k0 + j) * 64 + lane]);
+#pragma unroll
+                for (int a = 0; a < NT; ++a) {
+                    const bf16x8 wv = __builtin_bit_cast(bf16x8, w[a][j]);
+#pragma unroll
+                    for (int b = 0; b < MT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, bx[b], acc[a][b], 0, 0, 0);
+                }
+            }
+    };
+    const int nchunks = kts / KC;
+    stage(0, 0);
+    issue_w(0, wA);
+    issue_w(SC, wB);
+    for (int c = 0; c < nchunks; ++c) {
+        // as lmhead_kernel: after the first chunk only this wave's x stage is waited for, the KC/SC weight sets issued
+        // after it stay in flight across the barrier
+        if (c == 0) __syncthreads();
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((KC / SC) * NT * SC) : "memory");
+        if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int base = c * KC, buf = c & 1;
+#define NVLLM_ST_STEP(k0_, set_, next_)            \
+    compute(k0_, buf, set_);                       \
+    __builtin_amdgcn_sched_barrier(0);             \
+    issue_w(next_, set_);                          \
+    __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SC == 4) {
+            NVLLM_ST_STEP(0, wA, base + 8)
+            NVLLM_ST_STEP(4, wB, base + 12)
+        } else {
+            static_assert(SC == 2, "sets of 2 or 4 k-tiles");
+            NVLLM_ST_STEP(0, wA, base + 4)
+            NVLLM_ST_STEP(2, wB, base + 6)
+            NVLLM_ST_STEP(4, wA, base + 8)
+            NVLLM_ST_STEP(6, wB, base + 10)
+        }
+#undef NVLLM_ST_STEP
+    }
+    float* o = out + (size_t)blockIdx.y * (size_t)M * N;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        if (nt0 + a >= ntiles) continue;
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+            const int row = b * 16 + l15;
+            if (row < M) {
+                const f32x4 v = acc[a][b];
+                *reinterpret_cast<float4*>(o + (size_t)row * N + (size_t)(nt0 + a) * 16 + grp * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+// (NT, K slices) of the streaming GEMM: about one 8-wave workgroup per CU; nt == 0 -> not applicable
+struct StreamShape { int nt, ks; };
+static StreamShape stream_shape(int M, int N, int K) {
+    StreamShape none{0, 0};
+    static const bool off = getenv("NVLLM_NO_STREAM") != nullptr;
+    if (off || M <= 16 || M > 64 || N % 16 || K % 256 || (size_t)N * K * 2 < ((size_t)24 << 20)) return none;
+    const int KT = K / 32, ntiles = N / 16;
+    StreamShape best = none;
+    int best_wgs = 0;
+    for (int nt = 3; nt >= 1; --nt)
+        for (int ks = 1; ks <= 16; ++ks) {
+            if (KT % ks || (KT / ks) % 8 || KT / ks < 16) continue;
+            const int wgs = (((ntiles + nt - 1) / nt + 7) / 8) * ks;
+            // most workgroups within one round of the chip; ties go to fewer slices (fewer slabs for the consumer)
+            if (wgs <= 256 && (wgs > best_wgs || (wgs == best_wgs && ks < best.ks))) { best_wgs = wgs; best = StreamShape{nt, ks}; }
+        }
+    return best_wgs >= 128 ? best : none;
+}
+int gemm_stream_splits(int M, int N, int K) { return stream_shape(M, N, K).ks; }
+
+template <int NT, int SC>
+static hipError_t stream_launch_t(const StreamShape& sh, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
+                                  float* out, int M, int x_packed, hipStream_t s) {
+    const size_t lds = (size_t)2 * (2 * 4 * 8) * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<NT, SC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int waves = (w.N / 16 + NT - 1) / NT;
+    dim3 grid((waves + 7) / 8, sh.ks);
+    gemm_stream_kernel<NT, SC><<<grid, 512, lds, s>>>(xh, xl, ldx, w.data, out, M, w.N, w.K / 32, w.K / 32 / sh.ks, x_packed);
+    return hipGetLastError();
+}
+hipError_t launch_gemm_stream(const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w, float* out, int M, int x_packed,
+                              hipStream_t s) {
+    const StreamShape sh = stream_shape(M, w.N, w.K);
+    if (!sh.nt || ldx != w.K) return hipErrorNotSupported;
+    // set depth made no difference on MI355X (2- vs 4-k-tile sets, tools/probe_lm.py): the shallow ones use fewer registers
+    if (sh.nt == 1) return stream_launch_t<1, 4>(sh, xh, xl, ldx, w, out, M, x_packed, s);
+    if (sh.nt == 2) return stream_launch_t<2, 2>(sh, xh, xl, ldx, w, out, M, x_packed, s);
+    return stream_launch_t<3, 2>(sh, xh, xl, ldx, w, out, M, x_packed, s);
+}
+
 GemmPlan plan_lmhead(int M, int N, int K) {
     GemmPlan p = plan_gemm(M, N, K, 1);
     static const bool off = getenv("NVLLM_NO_LMHEAD") != nullptr;
@@ -2006,7 +2164,7 @@ __global__ void __launch_bounds__(256) silu_mul_kernel(const float* __restrict__
 // same for the INTERLEAVED gate/up layout of the packed weight (16-row tiles: gate tile, up tile, gate tile, ...)
 __global__ void __launch_bounds__(256) silu_mul_interleaved_kernel(const float* __restrict__ gu, int n_slabs,
                                                                   int64_t slab_stride, int rows, int I,
-                                                                  uint16_t* __restrict__ hi, uint16_t* __restrict__ lo) {
+                                                                  uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int out_packed) {
     const int64_t total = (int64_t)rows * (I >> 2);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / (I >> 2));
@@ -2024,15 +2182,16 @@ __global__ void __launch_bounds__(256) silu_mul_interleaved_kernel(const float* 
         const float y2 = (g.z / (1.0f + __expf(-g.z))) * u.z, y3 = (g.w / (1.0f + __expf(-g.w))) * u.w;
         uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
         split_bf16(y0, h0, l0); split_bf16(y1, h1, l1); split_bf16(y2, h2, l2); split_bf16(y3, h3, l3);
-        *reinterpret_cast<uint2*>(hi + (size_t)r * I + c) = make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
-        *reinterpret_cast<uint2*>(lo + (size_t)r * I + c) = make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
+        const size_t o = out_packed ? xpack_off(r, c, I >> 5) : (size_t)r * I + c;
+        *reinterpret_cast<uint2*>(hi + o) = make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
+        *reinterpret_cast<uint2*>(lo + o) = make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
     }
 }
 hipError_t launch_silu_mul_interleaved(const float* gu, int n_slabs, int64_t slab_stride, int rows, int I, bf16_bits* hi,
-                                       bf16_bits* lo, hipStream_t s) {
-    if (I % 16 != 0) return hipErrorInvalidValue;
+                                       bf16_bits* lo, int out_packed, hipStream_t s) {
+    if (I % 16 != 0 || (out_packed && I % 32)) return hipErrorInvalidValue;
     if (rows <= 0) return hipSuccess;
-    silu_mul_interleaved_kernel<<<grid_for((int64_t)rows * (I / 4)), 256, 0, s>>>(gu, n_slabs, slab_stride, rows, I, hi, lo);
+    silu_mul_interleaved_kernel<<<grid_for((int64_t)rows * (I / 4)), 256, 0, s>>>(gu, n_slabs, slab_stride, rows, I, hi, lo, out_packed);
     return hipGetLastError();
 }
 

@@ -264,6 +264,29 @@ def test_0_6b_layer_shapes_fused_decode_vs_oracle(pkg, ctx, oracle):
                 s_.append(int(t))
 
 
+def test_8b_layer_shapes_streaming_decode_vs_oracle(pkg, ctx, oracle):
+    # the generic decode path at Qwen3-8B LAYER shapes (H 4096, 32/8 heads of 128, I 12288: every projection is a
+    # >= 24 MB matrix -> K-sliced streaming GEMM + slab-summing consumers) on a 1-layer, 4096-token-vocabulary model:
+    # 20 sequences (17..64 rows select the streaming kernel), prefill + 2 decode steps
+    cfg = pkg.Qwen3Config.tiny(vocab_size=4096, hidden_size=4096, head_dim=128, num_hidden_layers=1,
+                               num_attention_heads=32, num_key_value_heads=8, intermediate_size=12288)
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
+    m.kv_alloc(32, 24, 1024)
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(0)
+    rng = np.random.default_rng(6)
+    sids = list(range(20))
+    seqs = [rng.integers(0, cfg.vocab_size, int(n)).tolist() for n in rng.integers(3, 33, 20)]
+    for step in range(3):
+        ids, lg = m.step(sids, seqs, step == 0, want_logits=True)
+        rid, rlg = om.run_greedy(seqs)
+        assert row_rel_err(lg, rlg) < LOGITS_TOL, step
+        srt = np.sort(rlg, axis=1)
+        clear = (srt[:, -1] - srt[:, -2]) / np.abs(rlg).max(axis=1) > 2 * LOGITS_TOL
+        assert (ids == rid)[clear].all(), step
+        for s_, t_ in zip(seqs, rid):
+            s_.append(int(t_))
+
+
 def test_full_size_batch64_properties(pkg, ctx):
     # BASELINE configs[2] size (0.6B, 64 live sequences): size-independent properties
     cfg = pkg.Qwen3Config.qwen3_0_6b()
