@@ -264,12 +264,15 @@ def test_0_6b_layer_shapes_fused_decode_vs_oracle(pkg, ctx, oracle):
                 s_.append(int(t))
 
 
-def test_8b_layer_shapes_streaming_decode_vs_oracle(pkg, ctx, oracle):
+@pytest.mark.parametrize("inter", [12288, 2048])
+def test_8b_layer_shapes_streaming_decode_vs_oracle(pkg, ctx, oracle, inter):
     # the generic decode path at Qwen3-8B LAYER shapes (H 4096, 32/8 heads of 128, I 12288: every projection is a
-    # >= 24 MB matrix -> K-sliced streaming GEMM + slab-summing consumers) on a 1-layer, 4096-token-vocabulary model:
-    # 20 sequences (17..64 rows select the streaming kernel), prefill + 2 decode steps
+    # >= 24 MB matrix -> K-sliced streaming GEMM on packed activation planes + slab-summing consumers) on a 1-layer,
+    # 4096-token-vocabulary model: 20 sequences (17..64 rows select the streaming kernel), prefill + 2 decode steps.
+    # I = 2048 makes down_proj a small matrix: the layer then mixes streaming GEMMs on ROW-MAJOR planes (the
+    # tensor-parallel shard case) with the register-direct kernel.
     cfg = pkg.Qwen3Config.tiny(vocab_size=4096, hidden_size=4096, head_dim=128, num_hidden_layers=1,
-                               num_attention_heads=32, num_key_value_heads=8, intermediate_size=12288)
+                               num_attention_heads=32, num_key_value_heads=8, intermediate_size=inter)
     m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
     m.kv_alloc(32, 24, 1024)
     om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(0)
