@@ -1530,11 +1530,18 @@ __global__ void __launch_bounds__(256) add_rmsnorm_kernel(NormArgs a) {
                 s = make_float4(bf16_to_f32(e.x & 0xffff), bf16_to_f32(e.x >> 16), bf16_to_f32(e.y & 0xffff),
                                 bf16_to_f32(e.y >> 16));
             } else {
-                s = *reinterpret_cast<const float4*>(a.in + (size_t)src * H + (size_t)i * 4);
-                for (int sl = 1; sl < a.n_slabs; ++sl) {
-                    const float4 t =
-                        *reinterpret_cast<const float4*>(a.in + (size_t)sl * a.slab_stride + (size_t)src * H + (size_t)i * 4);
-                    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                const float* pin = a.in + (size_t)src * H + (size_t)i * 4;
+                s = *reinterpret_cast<const float4*>(pin);
+                // split-K slabs, four at a time: the loads of a batch are independent (slab index clamped, the sum is
+                // masked) -- one load per loop trip costs a full round trip per slab (8-16 slabs on the 8B/32B shapes)
+                for (int sl0 = 1; sl0 < a.n_slabs; sl0 += 4) {
+                    float4 t[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        t[u] = *reinterpret_cast<const float4*>(pin + (size_t)min(sl0 + u, a.n_slabs - 1) * a.slab_stride);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (sl0 + u < a.n_slabs) { s.x += t[u].x; s.y += t[u].y; s.z += t[u].z; s.w += t[u].w; }
                 }
             }
             if (a.residual_in) {
@@ -1811,13 +1818,28 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
         // (contexts of <= 4 tiles only).
         load_tile(min(t_begin + wave, t_end - 1), kaA, kbA, vfA);
         const float ri = a.rn.ssq ? 1.0f / sqrtf(wave_sum(ssq_g) * a.rn.inv_h + a.rn.eps) : 1.0f;
-        for (int sl = 1; sl < a.n_slabs; ++sl) {  // split-K partials of a generic QKV GEMM (rare on this path)
-            const size_t so = (size_t)sl * a.slab_stride;
-            if (wave == 0) { kx1 += pk[so + ln]; kx2 += pk[so + ln + half]; vx1 += pv[so + ln]; vx2 += pv[so + ln + half]; }
+        for (int sl0 = 1; sl0 < a.n_slabs; sl0 += 2) {  // split-K slabs of the generic path's QKV GEMM, two per trip
+            const size_t so0 = (size_t)sl0 * a.slab_stride, so1 = (size_t)min(sl0 + 1, a.n_slabs - 1) * a.slab_stride;
+            const float m1 = sl0 + 1 < a.n_slabs ? 1.f : 0.f;
+            if (wave == 0) {
+                const float a0 = pk[so0 + ln], a1 = pk[so0 + ln + half], a2 = pv[so0 + ln], a3 = pv[so0 + ln + half];
+                const float b0 = pk[so1 + ln], b1 = pk[so1 + ln + half], b2 = pv[so1 + ln], b3 = pv[so1 + ln + half];
+                kx1 += a0; kx2 += a1; vx1 += a2; vx2 += a3;
+                kx1 += m1 * b0; kx2 += m1 * b1; vx1 += m1 * b2; vx2 += m1 * b3;
+            }
+            float4 q0[DC][2], q1[DC][2];
 #pragma unroll
-            for (int c = 0; c < DC; ++c)
+            for (int c = 0; c < DC; ++c) {
+                q0[c][0] = *reinterpret_cast<const float4*>(pq + so0 + c * 32); q0[c][1] = *reinterpret_cast<const float4*>(pq + so0 + c * 32 + 4);
+                q1[c][0] = *reinterpret_cast<const float4*>(pq + so1 + c * 32); q1[c][1] = *reinterpret_cast<const float4*>(pq + so1 + c * 32 + 4);
+            }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[c][j] += pq[so + c * 32 + j];
+            for (int c = 0; c < DC; ++c) {
+                x[c][0] += q0[c][0].x; x[c][1] += q0[c][0].y; x[c][2] += q0[c][0].z; x[c][3] += q0[c][0].w;
+                x[c][4] += q0[c][1].x; x[c][5] += q0[c][1].y; x[c][6] += q0[c][1].z; x[c][7] += q0[c][1].w;
+                x[c][0] += m1 * q1[c][0].x; x[c][1] += m1 * q1[c][0].y; x[c][2] += m1 * q1[c][0].z; x[c][3] += m1 * q1[c][0].w;
+                x[c][4] += m1 * q1[c][1].x; x[c][5] += m1 * q1[c][1].y; x[c][6] += m1 * q1[c][1].z; x[c][7] += m1 * q1[c][1].w;
+            }
         }
         // ---- K / V of the new token (wave 0 of the owning workgroup)
         if (wave == 0) {
@@ -2172,11 +2194,20 @@ __global__ void __launch_bounds__(256) silu_mul_interleaved_kernel(const float* 
         const float* pg = gu + (size_t)r * 2 * I + (size_t)(c >> 4) * 32 + (c & 15);
         float4 g = *reinterpret_cast<const float4*>(pg);
         float4 u = *reinterpret_cast<const float4*>(pg + 16);
-        for (int sl = 1; sl < n_slabs; ++sl) {
-            const float4 g2 = *reinterpret_cast<const float4*>(pg + (size_t)sl * slab_stride);
-            const float4 u2 = *reinterpret_cast<const float4*>(pg + (size_t)sl * slab_stride + 16);
-            g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
-            u.x += u2.x; u.y += u2.y; u.z += u2.z; u.w += u2.w;
+        for (int sl0 = 1; sl0 < n_slabs; sl0 += 4) {  // four slabs per trip, independent loads (clamped index, masked sum)
+            float4 g2[4], u2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t so = (size_t)min(sl0 + q, n_slabs - 1) * slab_stride;
+                g2[q] = *reinterpret_cast<const float4*>(pg + so);
+                u2[q] = *reinterpret_cast<const float4*>(pg + so + 16);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (sl0 + q < n_slabs) {
+                    g.x += g2[q].x; g.y += g2[q].y; g.z += g2[q].z; g.w += g2[q].w;
+                    u.x += u2[q].x; u.y += u2[q].y; u.z += u2[q].z; u.w += u2[q].w;
+                }
         }
         const float y0 = (g.x / (1.0f + __expf(-g.x))) * u.x, y1 = (g.y / (1.0f + __expf(-g.y))) * u.y;
         const float y2 = (g.z / (1.0f + __expf(-g.z))) * u.z, y3 = (g.w / (1.0f + __expf(-g.w))) * u.w;
