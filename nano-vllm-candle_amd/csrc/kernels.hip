@@ -1513,16 +1513,20 @@ hipError_t launch_gemm_rowpar(const RowParArgs& a, const PackedW& w, int epi, hi
 // ---------------------------------------------------------------------------------------------------
 constexpr int kNormMaxV4 = 8;  // per-thread float4 cache: H <= 256*4*8 = 8192
 
-__global__ void __launch_bounds__(256) add_rmsnorm_kernel(NormArgs a) {
-    __shared__ float red[4];
+// BS = 256 (many rows: prefill) or 1024 (<= 128 rows: decode has only `rows` workgroups, so each one gets 16 waves
+// and every thread's loads -- one float4 per slab -- are all in flight at once)
+template <int BS>
+__global__ void __launch_bounds__(BS) add_rmsnorm_kernel(NormArgs a) {
+    constexpr int NV = kNormMaxV4 * 256 / BS;
+    __shared__ float red[BS / 64];
     const int r = blockIdx.x;
     const int src = a.row_idx ? a.row_idx[r] : r;
     const int H = a.H, nv4 = H >> 2;
-    float4 cache[kNormMaxV4];
+    float4 cache[NV];
     float ss = 0.f;
 #pragma unroll
-    for (int c = 0; c < kNormMaxV4; ++c) {
-        const int i = threadIdx.x + c * 256;
+    for (int c = 0; c < NV; ++c) {
+        const int i = threadIdx.x + c * BS;
         if (i < nv4) {
             float4 s;
             if (a.ids) {
@@ -1556,13 +1560,15 @@ __global__ void __launch_bounds__(256) add_rmsnorm_kernel(NormArgs a) {
     ss = wave_sum(ss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
-    ss = red[0] + red[1] + red[2] + red[3];
+    ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < BS / 64; ++q) ss += red[q];
     // prep mode: leave the 1/rms factor to the consumer (RowNorm) and publish the row's sum of squares
     const float rinv = a.ssq_out ? 1.0f : 1.0f / sqrtf(ss / (float)H + a.eps);
     if (a.ssq_out && threadIdx.x == 0) a.ssq_out[r] = ss;
 #pragma unroll
-    for (int c = 0; c < kNormMaxV4; ++c) {
-        const int i = threadIdx.x + c * 256;
+    for (int c = 0; c < NV; ++c) {
+        const int i = threadIdx.x + c * BS;
         if (i < nv4) {
             const float4 s = cache[c];
             const float4 w = *reinterpret_cast<const float4*>(a.weight + (size_t)i * 4);
@@ -1582,7 +1588,8 @@ __global__ void __launch_bounds__(256) add_rmsnorm_kernel(NormArgs a) {
 hipError_t launch_add_rmsnorm(const NormArgs& a, int rows, hipStream_t s) {
     if (a.H % 4 != 0 || a.H > 256 * 4 * kNormMaxV4) return hipErrorInvalidValue;
     if (rows <= 0) return hipSuccess;
-    add_rmsnorm_kernel<<<rows, 256, 0, s>>>(a);
+    if (rows <= 128 && a.H >= 2048) add_rmsnorm_kernel<1024><<<rows, 1024, 0, s>>>(a);
+    else add_rmsnorm_kernel<256><<<rows, 256, 0, s>>>(a);
     return hipGetLastError();
 }
 
