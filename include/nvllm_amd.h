@@ -141,19 +141,6 @@ int nvllm_decode_collect(nvllm_model* m, uint32_t* next_ids);
 /* per-decode-step algorithmic HBM bytes of the LAST step on this rank:
  * weight_bytes + sum_seq ctx*kv_tok + n_seqs*kv_tok (+ 4*n_seqs*vocab when logits left the device) */
 int64_t nvllm_last_step_bytes(const nvllm_model* m);
-/* HIP-event timing of one kernel class on the library stream (bench.py's roofline leg):
- * kind 0 off, 1 paged attention, 2 layer GEMMs, 3 add+RMSNorm, 4 qk-norm/RoPE/KV-write, 5 SwiGLU, 6 LM head,
- * 7 calibration (an event pair around NO launch, recorded where the decode attention launch sits: the elapsed
- * time of an empty bracket between busy kernels, to be subtracted from the bracketed durations).
- * While a kind is set every launch of that class is bracketed by two events; read returns the summed
- * elapsed ms and the number of launches since the last read. */
-int nvllm_profile_kernel(nvllm_model* m, int kind);
-int nvllm_profile_read(nvllm_model* m, double* total_ms, int64_t* launches);
-/* copy per-layer taps of the last step to the host (debug/parity): what = 0 layer output h,
- * 1 residual; [rows, hidden] f32 of layer `layer`; rows = rows of the last step's last chunk */
-int nvllm_debug_layer_tap(nvllm_model* m, int layer, int what, float* out, int64_t capacity_floats);
-int nvllm_debug_enable_taps(nvllm_model* m, int enable);
-
 /* ---- fine seam: single ops on raw DEVICE pointers, launched on the context stream.
  * Shapes in elements; all f32 unless noted; tensors dense row-major. */
 
@@ -197,24 +184,6 @@ int nvllm_op_allreduce(nvllm_ctx* ctx, float* buf, int64_t count);
  * into a HOST buffer (generated on the GPU, copied back) */
 int nvllm_op_synth_bf16(nvllm_ctx* ctx, const char* name, uint64_t seed, int kind, int64_t first, int64_t count,
                         uint16_t* host_out);
-
-/* tuning aid: time one decomposition (n-tiles per wave, waves per workgroup, K splits; 0 = planner's choice)
- * of y[M,N] = x[M,K].W^T on synthetic operands; returns microseconds per launch */
-int nvllm_debug_gemm_bench(nvllm_ctx* ctx, int M, int N, int K, int nt, int nw, int n_split, int iters,
-                           float* us_per_call);
-
-/* tuning aid v2: explicit m-tiles per workgroup, epilogue mode (0 slabs, 2 SwiGLU with N = 2I) and `rot` weight
- * copies cycled per launch (cold HBM like the model; 1 = cache-warm) */
-int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int mt, int nt, int nw, int n_split, int mode, int rot,
-                            int iters, float* us_per_call);
-
-/* tuning aid: time the decode attention (one new token per sequence, ctx_lens[B] cached tokens each) on a
- * synthetic cache; part_tokens > 0 splits every context into workgroups of that many tokens */
-int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int hd, const int32_t* ctx_lens, int part_tokens,
-                           int iters, float* us_per_call);
-
-/* debug: XCC_ID (which of the 8 XCDs) every workgroup of a (gx,gy,gz) grid lands on; out[linear workgroup id] */
-int nvllm_debug_xcc_map(nvllm_ctx* ctx, int gx, int gy, int gz, int threads, int32_t* out);
 
 /* device memory helpers so a non-HIP host (Rust, ctypes) can feed the nvllm_op_* calls */
 int nvllm_dev_alloc(nvllm_ctx* ctx, size_t bytes, void** out);

@@ -1,0 +1,52 @@
+/*
+ * nvllm_amd_debug.h -- profiling, parity-debug and kernel-tuning entry points of libnvllm_amd.so.
+ *
+ * NOT part of the boundary a maintainer of the reference binds (that is include/nvllm_amd.h: the ModelRunner::run
+ * seam, src/engine/llm_engine.rs:16-18,145-189, and the layer surface, src/layers/).  These exports exist for
+ * bench.py (per-kernel HIP-event timing), the parity tests (per-layer taps, the Qwen3DecoderLayer::forward
+ * (h, residual) pair of src/models/qwen3.rs:374-399) and the tools/ tuning scripts.  Same conventions as the main header.
+ */
+#ifndef NVLLM_AMD_DEBUG_H
+#define NVLLM_AMD_DEBUG_H
+
+#include "nvllm_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HIP-event timing of one kernel class on the library stream (bench.py's roofline leg):
+ * kind 0 off, 1 paged attention, 2 layer GEMMs, 3 add+RMSNorm, 4 qk-norm/RoPE/KV-write, 5 SwiGLU, 6 LM head,
+ * 7 calibration (an event pair around NO launch, recorded where the decode attention launch sits: the elapsed
+ * time of an empty bracket between busy kernels, to be subtracted from the bracketed durations).
+ * While a kind is set every launch of that class is bracketed by two events; read returns the summed
+ * elapsed ms and the number of launches since the last read. */
+int nvllm_profile_kernel(nvllm_model* m, int kind);
+int nvllm_profile_read(nvllm_model* m, double* total_ms, int64_t* launches);
+/* copy per-layer taps of the last step to the host (debug/parity): what = 0 layer output h,
+ * 1 residual; [rows, hidden] f32 of layer `layer`; rows = rows of the last step's last chunk */
+int nvllm_debug_layer_tap(nvllm_model* m, int layer, int what, float* out, int64_t capacity_floats);
+int nvllm_debug_enable_taps(nvllm_model* m, int enable);
+
+/* tuning aid: time one decomposition (n-tiles per wave, waves per workgroup, K splits; 0 = planner's choice)
+ * of y[M,N] = x[M,K].W^T on synthetic operands; returns microseconds per launch */
+int nvllm_debug_gemm_bench(nvllm_ctx* ctx, int M, int N, int K, int nt, int nw, int n_split, int iters,
+                           float* us_per_call);
+
+/* tuning aid v2: explicit m-tiles per workgroup, epilogue mode (0 slabs, 2 SwiGLU with N = 2I) and `rot` weight
+ * copies cycled per launch (cold HBM like the model; 1 = cache-warm) */
+int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int mt, int nt, int nw, int n_split, int mode, int rot,
+                            int iters, float* us_per_call);
+
+/* tuning aid: time the decode attention (one new token per sequence, ctx_lens[B] cached tokens each) on a
+ * synthetic cache; part_tokens > 0 splits every context into workgroups of that many tokens */
+int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int hd, const int32_t* ctx_lens, int part_tokens,
+                           int iters, float* us_per_call);
+
+/* debug: XCC_ID (which of the 8 XCDs) every workgroup of a (gx,gy,gz) grid lands on; out[linear workgroup id] */
+int nvllm_debug_xcc_map(nvllm_ctx* ctx, int gx, int gy, int gz, int threads, int32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVLLM_AMD_DEBUG_H */

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/nvllm_amd.h"
+#include "../../include/nvllm_amd_debug.h"
 #include "kernels.h"
 #include "synth_device.h"
 
@@ -155,7 +156,12 @@ extern "C" int nvllm_rccl_unique_id(void* out_id) {
 extern "C" int nvllm_ctx_create(int device_ordinal, int tp_rank, int tp_size, const void* rccl_id, nvllm_ctx** out) {
     if (!out) return fail(nullptr, NVLLM_EINVAL, "out is NULL");
     if (tp_size < 1) return fail(nullptr, NVLLM_EINVAL, "tp_size must be >= 1");
-    if (tp_rank < 0 || tp_rank >= tp_size) tp_rank = 0;  // src/tp.rs:24-29
+    // src/tp.rs:24-29 folds a bad rank to 0, which is harmless there (no communicator exists); with a real RCCL
+    // group two "rank 0" processes would hang the rendezvous, so an out-of-range rank is an error here and the
+    // fold stays in the host mirror only (TPConfig.from_env)
+    if (tp_size > 1 && (tp_rank < 0 || tp_rank >= tp_size))
+        return fail(nullptr, NVLLM_EINVAL, "tp_rank %d outside [0, %d)", tp_rank, tp_size);
+    if (tp_rank < 0 || tp_rank >= tp_size) tp_rank = 0;
     int ndev = 0;
     HIPCHK(nullptr, hipGetDeviceCount(&ndev));
     if (device_ordinal < 0 || device_ordinal >= ndev)
@@ -660,10 +666,18 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     free_kv(m);
+    // a second kv_alloc starts from a clean slate: no sequence, no resident decode batch, no step in flight
     m->seqs.clear();
+    m->last_ids.clear();
+    m->last_lens.clear();
+    m->pending.clear();
+    m->pend_next = 0;
+    m->decode_resident = false;
+    if (m->pin_ids) { (void)hipHostFree(m->pin_ids); m->pin_ids = nullptr; }  // sized by the old max_seqs
     m->num_blocks = num_blocks;
     m->max_seqs = max_seqs;
-    m->max_rows = std::max(max_batched_tokens, 16);
+    // every row-sized buffer holds max_rows rows; a decode step has one row per sequence, so max_seqs rows must fit
+    m->max_rows = std::max({max_batched_tokens, max_seqs, 16});
     const int by_pos = (m->cfg.max_position_embeddings + kBlockTokens - 1) / kBlockTokens;
     m->max_blocks = std::max(1, std::min(num_blocks, by_pos));
     const size_t per_layer = (size_t)num_blocks * m->kv_l * kBlockTokens * m->hd;
@@ -682,7 +696,7 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     for (int i = 0; i < max_seqs; ++i) m->free_slots[i] = max_seqs - 1 - i;
     m->h_block_tables.assign((size_t)max_seqs * m->max_blocks, 0);
     int rc = dmalloc(ctx, &m->d_block_tables, (size_t)max_seqs * m->max_blocks);
-    HIPCHK(ctx, hipMemsetAsync(m->d_block_tables, 0, (size_t)max_seqs * m->max_blocks * 4, ctx->stream));
+    if (!rc) HIPCHK(ctx, hipMemsetAsync(m->d_block_tables, 0, (size_t)max_seqs * m->max_blocks * 4, ctx->stream));
     const size_t R = m->max_rows;
     const size_t wide = std::max<size_t>({(size_t)m->H, (size_t)m->nh_l * m->hd, (size_t)m->I_l});
     const size_t nmax = std::max<size_t>({(size_t)(m->nh_l + 2 * m->kv_l) * m->hd, (size_t)m->H, (size_t)2 * m->I_l});
@@ -900,8 +914,7 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
                 PROF(m, PROF_GEMM, launch_gemm_rowpar(rg, w.gu, 1, s));
             } else {
                 GemmPlan pg = plan_gemm_swiglu(R, 2 * m->I_l, H);
-                gemm_set_rownorm(&rn);
-                PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, s));
+                PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, &rn, s));
             }
         }
         // down_proj + residual + next layer's input norm prep (qwen3.rs:326, next layer :378; last layer: final norm :497)
@@ -918,8 +931,7 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
         GemmPlan pl = plan_lmhead(n_last, m->V_l, H);
         float* lg = m->want_logits ? m->logits + (size_t)logits_row0 * m->V_l : nullptr;
         rn.row_idx = m->d_last_rows;
-        gemm_set_rownorm(&rn);
-        PROF(m, PROF_LMHEAD, launch_gemm_argmax(pl, m->xh, m->xl, H, m->lm_head, lg, n_last, m->part_val, m->part_idx, s));
+        PROF(m, PROF_LMHEAD, launch_gemm_argmax(pl, m->xh, m->xl, H, m->lm_head, lg, n_last, m->part_val, m->part_idx, &rn, s));
         if (pl.lm_nt > 0)
             HIPCHK(ctx, launch_argmax_rows(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, m->d_next + logits_row0, nullptr, s));
         else
@@ -1041,7 +1053,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         } else {
             // gate/up GEMM with the SiLU*mul epilogue: act hi/lo written directly, no slabs, no extra launch
             GemmPlan pg = plan_gemm_swiglu(R, 2 * m->I_l, H);
-            PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, s));
+            PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, nullptr, s));
         }
         int d_slabs = 1;
         rcg = gemm_slabs(m, m->xh2, m->xl2, m->I_l, w.down, m->slabs, R, 8, &d_slabs, packed);
@@ -1064,7 +1076,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         // logits are stored only when the caller asked for them; the greedy id always comes from the
         // GEMM epilogue's per-wave partial arg-max (LAST max wins), finished by one small kernel
         float* lg = m->want_logits ? m->logits + (size_t)logits_row0 * m->V_l : nullptr;
-        PROF(m, PROF_LMHEAD, launch_gemm_argmax(pl, m->xh, m->xl, H, m->lm_head, lg, n_last, m->part_val, m->part_idx, s));
+        PROF(m, PROF_LMHEAD, launch_gemm_argmax(pl, m->xh, m->xl, H, m->lm_head, lg, n_last, m->part_val, m->part_idx, nullptr, s));
         const int tp = ctx->tp_size;
         uint32_t* ids_dst = tp == 1 ? m->d_next + logits_row0 : m->d_next + m->cur_n + (size_t)ctx->tp_rank * m->cur_n + logits_row0;
         float* val_dst = tp == 1 ? nullptr : m->d_maxval + (size_t)ctx->tp_rank * m->cur_n + logits_row0;
@@ -1299,11 +1311,14 @@ static int decode_core(nvllm_model* m) {
     nvllm_ctx* ctx = m->ctx;
     const int n = (int)m->last_ids.size();
     if (n == 0) return fail(ctx, NVLLM_ESTATE, "no previous step to continue");
+    if (n > m->max_rows) return fail(ctx, NVLLM_ESTATE, "%d decode rows > %d rows of step buffers", n, m->max_rows);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     bool table_dirty = false;
     for (int i = 0; i < n; ++i) {
-        SeqState& st = m->seqs[m->last_ids[i]];
+        auto it = m->seqs.find(m->last_ids[i]);
+        if (it == m->seqs.end()) return fail(ctx, NVLLM_ESTATE, "sequence %lld of the previous step is gone", (long long)m->last_ids[i]);
+        SeqState& st = it->second;
         const int len = m->last_lens[i] + 1;
         if (len > m->rope_len) return fail(ctx, NVLLM_EINVAL, "sequence %d would exceed max positions %d", i, m->rope_len);
         const size_t before = st.blocks.size();
@@ -1367,7 +1382,8 @@ extern "C" int nvllm_decode_enqueue(nvllm_model* m) {
     if (rc) return rc;
     if (!m->pin_ids) {
         HIPCHK(ctx, hipHostMalloc((void**)&m->pin_ids, (size_t)kMaxPending * m->max_seqs * 4, hipHostMallocDefault));
-        for (int i = 0; i < kMaxPending; ++i) HIPCHK(ctx, hipEventCreateWithFlags(&m->pend_ev[i], hipEventDisableTiming));
+        for (int i = 0; i < kMaxPending; ++i)
+            if (!m->pend_ev[i]) HIPCHK(ctx, hipEventCreateWithFlags(&m->pend_ev[i], hipEventDisableTiming));
     }
     const int slot = m->pend_next;
     m->pend_next = (m->pend_next + 1) % kMaxPending;
@@ -1812,7 +1828,7 @@ extern "C" int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int 
     }
     auto go = [&](int i) -> hipError_t {
         const PackedW& w = ws[i % rot];
-        if (mode == 20 || mode == 21) return launch_gemm_argmax(plm, xh, xl, K, w, nullptr, M, pv, pi, s);
+        if (mode == 20 || mode == 21) return launch_gemm_argmax(plm, xh, xl, K, w, nullptr, M, pv, pi, nullptr, s);
         if (mode == 22 || mode == 23) return launch_gemm_stream(xh, xl, K, w, out, M, mode == 23, s);  // 23: packed x planes
         if (mode >= 10) {
             RowParArgs ra;
@@ -1821,7 +1837,7 @@ extern "C" int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int 
             ra.rn.ssq = ssq_in; ra.rn.groups = 1; ra.rn.stride = 128; ra.rn.inv_h = 1.0f / K; ra.rn.eps = 1e-6f;
             return launch_gemm_rowpar(ra, w, mode - 10, s);
         }
-        return mode == 2 ? launch_gemm_swiglu(p, xh, xl, K, w, M, ah, al, s) : launch_gemm(p, xh, xl, K, w, out, M, s);
+        return mode == 2 ? launch_gemm_swiglu(p, xh, xl, K, w, M, ah, al, nullptr, s) : launch_gemm(p, xh, xl, K, w, out, M, s);
     };
     for (int i = 0; i < 3; ++i) HIPCHK(ctx, go(i));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s));

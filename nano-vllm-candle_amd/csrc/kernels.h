@@ -82,16 +82,16 @@ GemmPlan plan_lmhead(int M, int N, int K);
 void set_split(GemmPlan& p, int KT, int want);
 hipError_t launch_gemm(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
                        float* out, int M, hipStream_t s);
-void gemm_set_rownorm(const RowNorm* rn);  // applies to the NEXT launch_gemm_argmax / launch_gemm_swiglu only
 // same GEMM (n_split must be 1) whose epilogue also emits per-wave partial arg-max (LAST max wins):
-// part_val/part_idx [gemm_argmax_parts(p, N)][M]; `out` may be nullptr (ids only, logits never stored)
+// part_val/part_idx [gemm_argmax_parts(p, N)][M]; `out` may be nullptr (ids only, logits never stored).
+// rn (nullable): deferred RMSNorm of the input rows, applied to the sums (RowNorm)
 hipError_t launch_gemm_argmax(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
-                              float* out, int M, float* part_val, int* part_idx, hipStream_t s);
+                              float* out, int M, float* part_val, int* part_idx, const RowNorm* rn, hipStream_t s);
 int gemm_argmax_parts(const GemmPlan& p, int N);
 // gate/up projection with the SiLU*mul epilogue (weight interleaved by launch_pack_rows(..., ileave))
 GemmPlan plan_gemm_swiglu(int M, int N2, int K);
 hipError_t launch_gemm_swiglu(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
-                              int M, bf16_bits* act_hi, bf16_bits* act_lo, hipStream_t s);
+                              int M, bf16_bits* act_hi, bf16_bits* act_lo, const RowNorm* rn, hipStream_t s);
 // scratch: 8*(M+1) bytes, zero before the first use (the kernel leaves it zero again)
 // finish of the streaming LM head (plan.lm_nt > 0): partials are [row][n_parts], one workgroup per row
 hipError_t launch_argmax_rows(const float* part_val, const int* part_idx, int n_parts, int M, uint32_t* ids, float* maxval, hipStream_t s);

@@ -7,6 +7,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "synth_device.h"
@@ -135,6 +136,18 @@ __global__ void __launch_bounds__(256) synth_rowmajor_f32_kernel(float* __restri
                                                                  int64_t first, int64_t count) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
         dst[i] = bf16_to_f32(synth_bits(name_hash, (uint64_t)(first + i), kind));
+}
+
+// hipFuncSetAttribute is per device: remember on which devices a kernel's dynamic-LDS limit has been raised
+// (one bit per device ordinal; idempotent, so a race between two host threads only repeats the call)
+static inline void ensure_dyn_lds(const void* fn, size_t lds, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        done.fetch_or(bit, std::memory_order_release);
+    }
 }
 
 static inline int grid_for(int64_t n, int per_block = 256, int cap = 8192) {
@@ -510,12 +523,8 @@ static hipError_t gemm_launch_t(const GemmPlan& p, const bf16_bits* xh, const bf
     const int ntiles = w.N / 16;
     dim3 grid((ntiles + NT * NW - 1) / (NT * NW), p.n_split, (M + MT * 16 - 1) / (MT * 16));
     const size_t lds = (size_t)2 * 2 * MT * KC * 1024 + (size_t)4 * MT * 16 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<MT, NT, NW, KC, MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_set{0};
+    ensure_dyn_lds(reinterpret_cast<const void*>(gemm_kernel<MT, NT, NW, KC, MODE>), lds, lds_set);
     gemm_kernel<MT, NT, NW, KC, MODE><<<grid, NW * 64, lds, s>>>(xh, xl, ldx, w.data, out, M, w.N, w.K / 32, p.kt_per_split,
                                                                 x.part_val, x.part_idx, x.act_hi, x.act_lo, x.rn);
     return hipGetLastError();
@@ -552,9 +561,6 @@ static hipError_t gemm_dispatch(const GemmPlan& p, const bf16_bits* xh, const bf
     if (p.nw == 8) return gemm_dispatch_nw<8, MODE>(p, xh, xl, ldx, w, out, M, x, s);
     return hipErrorInvalidValue;
 }
-
-static RowNorm g_next_rownorm;  // consumed (and cleared) by the next argmax / swiglu launch
-void gemm_set_rownorm(const RowNorm* rn) { g_next_rownorm = rn ? *rn : RowNorm{}; }
 
 hipError_t launch_gemm(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
                        float* out, int M, hipStream_t s) {
@@ -764,11 +770,8 @@ template <int MT, int NT, int NCH>
 static hipError_t lmhead_launch_t(const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w, float* out, int M,
                                   float* part_val, int* part_idx, const RowNorm& rn, hipStream_t s) {
     const size_t lds = (size_t)2 * (2 * MT * 8) * 1024 + (size_t)4 * MT * 16 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lmhead_kernel<MT, NT, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_set{0};
+    ensure_dyn_lds(reinterpret_cast<const void*>(lmhead_kernel<MT, NT, NCH>), lds, lds_set);
     const int waves = (w.N / 16 + NT - 1) / NT;
     lmhead_kernel<MT, NT, NCH><<<(waves + 7) / 8, 512, lds, s>>>(xh, xl, ldx, w.data, out, M, w.N, w.K / 32, part_val, part_idx, rn);
     return hipGetLastError();
@@ -912,11 +915,8 @@ template <int NT, int SC>
 static hipError_t stream_launch_t(const StreamShape& sh, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
                                   float* out, int M, int x_packed, hipStream_t s) {
     const size_t lds = (size_t)2 * (2 * 4 * 8) * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_stream_kernel<NT, SC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_set{0};
+    ensure_dyn_lds(reinterpret_cast<const void*>(gemm_stream_kernel<NT, SC>), lds, lds_set);
     const int waves = (w.N / 16 + NT - 1) / NT;
     dim3 grid((waves + 7) / 8, sh.ks);
     gemm_stream_kernel<NT, SC><<<grid, 512, lds, s>>>(xh, xl, ldx, w.data, out, M, w.N, w.K / 32, w.K / 32 / sh.ks, x_packed);
@@ -945,11 +945,11 @@ GemmPlan plan_lmhead(int M, int N, int K) {
 }
 
 hipError_t launch_gemm_argmax(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
-                              float* out, int M, float* part_val, int* part_idx, hipStream_t s) {
+                              float* out, int M, float* part_val, int* part_idx, const RowNorm* rn, hipStream_t s) {
     if (!part_val || !part_idx || p.n_split != 1) return hipErrorInvalidValue;
     GemmExtra x;
     x.part_val = part_val; x.part_idx = part_idx;
-    x.rn = g_next_rownorm; g_next_rownorm = RowNorm{};
+    if (rn) x.rn = *rn;
     if (p.lm_nt > 0) {
         if (M < 1 || M > 64 || w.K % 256) return hipErrorInvalidValue;
         const int mt = M <= 16 ? 1 : M <= 32 ? 2 : 4;
@@ -968,11 +968,11 @@ hipError_t launch_gemm_argmax(const GemmPlan& p, const bf16_bits* xh, const bf16
 
 // gate/up GEMM with the SwiGLU epilogue; w = interleaved gate_up [2I][K]; act planes [M][I]
 hipError_t launch_gemm_swiglu(const GemmPlan& p, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
-                              int M, bf16_bits* act_hi, bf16_bits* act_lo, hipStream_t s) {
+                              int M, bf16_bits* act_hi, bf16_bits* act_lo, const RowNorm* rn, hipStream_t s) {
     if (p.nt % 2 || p.n_split != 1 || !act_hi || !act_lo) return hipErrorInvalidValue;
     GemmExtra x;
     x.act_hi = act_hi; x.act_lo = act_lo;
-    x.rn = g_next_rownorm; g_next_rownorm = RowNorm{};
+    if (rn) x.rn = *rn;
     return gemm_dispatch<2>(p, xh, xl, ldx, w, nullptr, M, x, s);
 }
 GemmPlan plan_gemm_swiglu(int M, int N2, int K) {
@@ -1432,12 +1432,8 @@ int gemm_rowpar_splits(int N, int K, int epi, int M) {
 template <int NT, int NWK, int TK, int EPI>
 static hipError_t rowdir_launch_t(const RowParArgs& a, const PackedW& w, hipStream_t s) {
     const size_t lds = (size_t)NWK * NT * 1024 + (size_t)(NT > 4 ? NT : 4) * 16 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowdir_kernel<NT, NWK, TK, EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_set{0};
+    ensure_dyn_lds(reinterpret_cast<const void*>(gemm_rowdir_kernel<NT, NWK, TK, EPI>), lds, lds_set);
     dim3 grid((w.N / 16 + NT - 1) / NT, 1, (a.M + 15) / 16);
     gemm_rowdir_kernel<NT, NWK, TK, EPI><<<grid, NWK * 64, lds, s>>>(a, w.data, w.N, w.K / 32);
     return hipGetLastError();
@@ -1456,12 +1452,8 @@ template <int MT, int NWN, int NWK, int TPW, int PH, int EPI>
 static hipError_t rowpar_launch_t(const RowParShape& sh, const RowParArgs& a, const PackedW& w, hipStream_t s) {
     constexpr int NW = NWN * NWK, KTP = NWK * TPW, NBUF = PH > 1 ? 2 : 1, IMG = 2 * MT * KTP;
     const size_t lds = std::max((size_t)NBUF * IMG * 1024, (size_t)NW * MT * 1024) + (size_t)4 * 16 * MT * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowpar_kernel<MT, NWN, NWK, TPW, PH, EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_set{0};
+    ensure_dyn_lds(reinterpret_cast<const void*>(gemm_rowpar_kernel<MT, NWN, NWK, TPW, PH, EPI>), lds, lds_set);
     dim3 grid((w.N / 16 + NWN - 1) / NWN, sh.ns, (a.M + 16 * MT - 1) / (16 * MT));
     gemm_rowpar_kernel<MT, NWN, NWK, TPW, PH, EPI><<<grid, NW * 64, lds, s>>>(a, w.data, w.N, w.K / 32);
     return hipGetLastError();
@@ -2124,12 +2116,8 @@ template <int HD, int QT, int NWV, bool FUSED>
 static hipError_t attn_launch_t(const AttnArgs& a, int n_tiles, int grid_z, hipStream_t s) {
     constexpr int DT = HD / 16;
     const size_t lds = (size_t)NWV * QT * 2 * 16 * 4 + (size_t)NWV * QT * DT * 64 * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_paged_kernel<HD, QT, NWV, FUSED>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_set{0};
+    ensure_dyn_lds(reinterpret_cast<const void*>(attn_paged_kernel<HD, QT, NWV, FUSED>), lds, lds_set);
     dim3 grid(n_tiles, a.kv.kv_l, grid_z);
     attn_paged_kernel<HD, QT, NWV, FUSED><<<grid, NWV * 64, lds, s>>>(a);
     return hipGetLastError();

@@ -1,6 +1,6 @@
 // Device-side deterministic synthetic-checkpoint generator.
 //
-// Independent implementation of the recipe the oracle documents (tests/test_synth.py checks the two
+// Independent implementation of the recipe the oracle documents (tests/test_ops_gpu.py::test_device_generator_matches_oracle_generator checks the two
 // for bit-equality through the C ABI):
 //   name_hash = FNV-1a-64(name) ^ (seed * 0x9E3779B97F4A7C15)
 //   h         = splitmix64 finalizer of (name_hash + (idx + 1) * 0x9E3779B97F4A7C15)

@@ -127,6 +127,20 @@ def read_safetensors(path):
         yield name, arr.reshape(meta["shape"]), code
 
 
+def checkpoint_files(model_dir):
+    """safetensors files of an HF model directory: the shards named by model.safetensors.index.json (each once, in
+    name order) or the single model.safetensors the reference expects (qwen3.rs:517-521; same error text)"""
+    idx = os.path.join(model_dir, "model.safetensors.index.json")
+    single = os.path.join(model_dir, "model.safetensors")
+    if os.path.exists(idx):
+        with open(idx) as f:
+            names = sorted(set(json.load(f)["weight_map"].values()))
+        return [os.path.join(model_dir, x) for x in names]
+    if os.path.exists(single):
+        return [single]
+    raise RuntimeError(f"mmap {single}: no such file")
+
+
 class Qwen3ForCausalLM:
     """src/models/qwen3.rs:503-551"""
 
@@ -145,17 +159,7 @@ class Qwen3ForCausalLM:
         """qwen3.rs:515-536 (+ sharded checkpoints and tied lm_head, which the reference cannot load: SURVEY F9)"""
         cfg = Qwen3Config.from_hf_dir(model_dir)
         m = cls(cfg, ctx)
-        files = []
-        idx = os.path.join(model_dir, "model.safetensors.index.json")
-        single = os.path.join(model_dir, "model.safetensors")
-        if os.path.exists(idx):
-            with open(idx) as f:
-                files = sorted(set(json.load(f)["weight_map"].values()))
-            files = [os.path.join(model_dir, x) for x in files]
-        elif os.path.exists(single):
-            files = [single]
-        else:
-            raise RuntimeError(f"mmap {single}: no such file")
+        files = checkpoint_files(model_dir)
         for path in files:
             for name, arr, code in read_safetensors(path):
                 m.load_tensor(name, arr, code)

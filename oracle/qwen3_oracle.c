@@ -59,17 +59,68 @@ typedef struct {
 /* ops                                                                                        */
 /* ------------------------------------------------------------------------------------------ */
 
-/* y[M,N] = x[M,K] . W[N,K]^T (+ bias[N]) -- candle_nn::Linear, src/layers/linear.rs:35-36,72-77,184-198 */
+/* y[M,N] = x[M,K] . W[N,K]^T (+ bias[N]) -- candle_nn::Linear, src/layers/linear.rs:35-36,72-77,184-198.
+ * Every output is a plain f32 dot product over k (candle's gemm leaves the f32 summation order
+ * implementation-defined, see the header).  Blocking below is for speed only (the parity tests run whole
+ * Qwen3-0.6B forwards): 4 rows of x against 2 rows of W per inner loop, 8 k-lanes of partial sums each,
+ * rows of x taken in chunks that stay cache-resident while the W rows stream past. */
+typedef float oq3_v8 __attribute__((vector_size(32)));
+static inline oq3_v8 oq3_ld8(const float* p) { oq3_v8 v; memcpy(&v, p, sizeof v); return v; }
+static inline float oq3_hsum8(oq3_v8 v) { return ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7])); }
+
+/* one dot product with the SAME arithmetic as an element of the blocked kernel below (8 k-lanes of partial sums,
+ * fixed reduction tree, scalar tail), so an output value never depends on how its row was blocked */
+static inline float oq3_dot(const float* a, const float* b, int K) {
+    const int K8 = K & ~7;
+    oq3_v8 v = {0};
+    for (int k = 0; k < K8; k += 8) v += oq3_ld8(a + k) * oq3_ld8(b + k);
+    float acc = oq3_hsum8(v);
+    for (int k = K8; k < K; ++k) acc += a[k] * b[k];
+    return acc;
+}
+
 OQ3_API void oq3_linear(const float* x, const float* W, const float* bias, int M, int K, int N, float* y) {
+    enum { MB = 4, NB = 2, MCHUNK = 128 };
+    const int K8 = K & ~7;
+    for (int m0 = 0; m0 < M; m0 += MCHUNK) {
+        const int m1 = m0 + MCHUNK < M ? m0 + MCHUNK : M;
+        const int mfull = m0 + ((m1 - m0) / MB) * MB;
 #pragma omp parallel for schedule(static)
-    for (int n = 0; n < N; ++n) {
-        const float* w = W + (size_t)n * K;
-        for (int m = 0; m < M; ++m) {
-            const float* xr = x + (size_t)m * K;
-            float acc = 0.f;
-#pragma omp simd reduction(+ : acc)
-            for (int k = 0; k < K; ++k) acc += xr[k] * w[k];
-            y[(size_t)m * N + n] = bias ? acc + bias[n] : acc;
+        for (int n0 = 0; n0 < N; n0 += NB) {
+            const int nn = n0 + NB <= N ? NB : N - n0;
+            if (nn == NB) {
+                const float* w0 = W + (size_t)n0 * K;
+                const float* w1 = w0 + K;
+                for (int m = m0; m < mfull; m += MB) {
+                    const float *x0 = x + (size_t)m * K, *x1 = x0 + K, *x2 = x1 + K, *x3 = x2 + K;
+                    oq3_v8 a00 = {0}, a01 = {0}, a10 = {0}, a11 = {0}, a20 = {0}, a21 = {0}, a30 = {0}, a31 = {0};
+                    for (int k = 0; k < K8; k += 8) {
+                        const oq3_v8 b0 = oq3_ld8(w0 + k), b1 = oq3_ld8(w1 + k);
+                        oq3_v8 xv = oq3_ld8(x0 + k); a00 += xv * b0; a01 += xv * b1;
+                        xv = oq3_ld8(x1 + k); a10 += xv * b0; a11 += xv * b1;
+                        xv = oq3_ld8(x2 + k); a20 += xv * b0; a21 += xv * b1;
+                        xv = oq3_ld8(x3 + k); a30 += xv * b0; a31 += xv * b1;
+                    }
+                    float r[MB][NB] = {{oq3_hsum8(a00), oq3_hsum8(a01)}, {oq3_hsum8(a10), oq3_hsum8(a11)},
+                                       {oq3_hsum8(a20), oq3_hsum8(a21)}, {oq3_hsum8(a30), oq3_hsum8(a31)}};
+                    for (int i = 0; i < MB; ++i)
+                        for (int j = 0; j < NB; ++j) {
+                            float acc = r[i][j];
+                            const float* xr = x + (size_t)(m + i) * K;
+                            const float* wr = W + (size_t)(n0 + j) * K;
+                            for (int k = K8; k < K; ++k) acc += xr[k] * wr[k];
+                            y[(size_t)(m + i) * N + n0 + j] = bias ? acc + bias[n0 + j] : acc;
+                        }
+                }
+            }
+            /* leftover rows of the chunk (and a last odd W row): one dot product per output */
+            for (int j = 0; j < nn; ++j) {
+                const float* wr = W + (size_t)(n0 + j) * K;
+                for (int m = (nn == NB ? mfull : m0); m < m1; ++m) {
+                    const float acc = oq3_dot(x + (size_t)m * K, wr, K);
+                    y[(size_t)m * N + n0 + j] = bias ? acc + bias[n0 + j] : acc;
+                }
+            }
         }
     }
 }
@@ -163,22 +214,25 @@ OQ3_API void oq3_attention(const float* q, const float* k, const float* v, int B
                 const float* kh = k + ((size_t)(b * kv + h / rep) * T) * hd;
                 const float* vh = v + ((size_t)(b * kv + h / rep) * T) * hd;
                 for (int i = 0; i < T; ++i) {
+                    /* Keys j > i carry the additive -1e9 mask (:260-271): after the row maximum is subtracted their
+                     * exp() is exactly 0 in f32 (the unmasked j == i score is finite), so they contribute nothing to
+                     * the sum or to p.v -- the loops below stop at j == i instead of computing those zeros. */
                     float mx = -INFINITY;
-                    for (int j = 0; j < T; ++j) {
-                        float acc = 0.f;
-                        for (int d = 0; d < hd; ++d) acc += qh[(size_t)i * hd + d] * kh[(size_t)j * hd + d];
-                        acc = acc * scale + (j > i ? -1e9f : 0.0f);
+                    for (int j = 0; j <= i; ++j) {
+                        const float acc = oq3_dot(qh + (size_t)i * hd, kh + (size_t)j * hd, hd) * scale;
                         sc[j] = acc;
                         if (acc > mx) mx = acc;
                     }
                     float sum = 0.f;
-                    for (int j = 0; j < T; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+                    for (int j = 0; j <= i; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
                     float* out = ctx + ((size_t)(b * T + i) * nh + h) * hd;
                     for (int d = 0; d < hd; ++d) out[d] = 0.f;
-                    for (int j = 0; j < T; ++j) {
-                        float p = sc[j] / sum;
-                        if (p == 0.f) continue; /* masked entries are exactly 0 in f32 */
-                        for (int d = 0; d < hd; ++d) out[d] += p * vh[(size_t)j * hd + d];
+                    for (int j = 0; j <= i; ++j) {
+                        const float p = sc[j] / sum;
+                        if (p == 0.f) continue;
+                        const float* vr = vh + (size_t)j * hd;
+#pragma omp simd
+                        for (int d = 0; d < hd; ++d) out[d] += p * vr[d];
                     }
                 }
             }

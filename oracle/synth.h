@@ -2,7 +2,7 @@
  * Deterministic synthetic-checkpoint generator (shared spec).
  *
  * TEST INFRASTRUCTURE (oracle side).  The same integer recipe is implemented twice, independently,
- * and tested for bit-equality (tests/test_synth.py): here (plain C, host, feeds the oracle) and in
+ * and tested for bit-equality (tests/test_ops_gpu.py::test_device_generator_matches_oracle_generator): here (plain C, host, feeds the oracle) and in
  * nano-vllm-candle_amd/csrc/synth_device.h (HIP, fills product weights straight into HBM).
  * The product never includes this file.
  *

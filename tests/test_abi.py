@@ -5,13 +5,22 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "nvllm_amd.h")
+HEADER = os.path.join(ROOT, "include", "nvllm_amd.h")              # the boundary a maintainer binds
+DEBUG_HEADER = os.path.join(ROOT, "include", "nvllm_amd_debug.h")  # profiling / parity-debug / tuning exports
 
 
-def header_functions():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(nvllm_[a-z0-9_]+)\s*\(", src)))
+def header_functions(paths=(HEADER, DEBUG_HEADER)):
+    names = set()
+    for path in paths:
+        src = open(path).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names.update(re.findall(r"\b(nvllm_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
+
+
+def test_boundary_header_holds_no_debug_or_tuning_exports():
+    names = header_functions((HEADER,))
+    assert not [n for n in names if "_debug_" in n or "_profile_" in n], names
 
 
 def test_library_exports_every_header_symbol():

@@ -8,7 +8,7 @@ import pytest
 
 import nano_vllm_candle_amd as pkg
 from nano_vllm_candle_amd.engine import LLMEngine, ModelRunner, SamplingParams, Scheduler, SchedulerConfig, Sequence
-from nano_vllm_candle_amd.qwen3 import Qwen3Config, read_safetensors
+from nano_vllm_candle_amd.qwen3 import Qwen3Config, checkpoint_files, read_safetensors
 from nano_vllm_candle_amd.tp import TPConfig, get_tp, shard_region
 
 
@@ -153,6 +153,17 @@ def test_safetensors_reader_roundtrip(tmp_path):
     got = {n: (arr.copy(), code) for n, arr, code in read_safetensors(str(p))}
     assert np.array_equal(got["x.weight"][0], a) and got["x.weight"][1] == pkg._lib.DTYPE_F32
     assert np.array_equal(got["y.weight"][0], b) and got["y.weight"][1] == pkg._lib.DTYPE_BF16
+
+
+def test_checkpoint_files_single_sharded_and_missing(tmp_path):
+    with pytest.raises(RuntimeError, match="no such file"):
+        checkpoint_files(str(tmp_path))
+    (tmp_path / "model.safetensors").write_bytes(b"")
+    assert checkpoint_files(str(tmp_path)) == [str(tmp_path / "model.safetensors")]
+    wm = {"a": "model-00002-of-00002.safetensors", "b": "model-00001-of-00002.safetensors", "c": "model-00002-of-00002.safetensors"}
+    (tmp_path / "model.safetensors.index.json").write_text(json.dumps({"weight_map": wm}))
+    assert checkpoint_files(str(tmp_path)) == [str(tmp_path / "model-00001-of-00002.safetensors"),
+                                               str(tmp_path / "model-00002-of-00002.safetensors")]  # the index wins; each shard once
 
 
 def test_hf_tensor_names_match_reference_loader():

@@ -196,9 +196,10 @@ def test_context_crossing_a_block_boundary(pkg, ctx, oracle):
         seq[0].append(int(rid[0]))
 
 
-def test_engine_continuous_batching_matches_single_sequence_runs(pkg, ctx):
-    # configs[2] in miniature: prefill-first scheduling with max_num_seqs 3; every request's tokens must equal
-    # the tokens it gets when it runs alone (sequences are independent; batching must not leak state)
+def test_engine_continuous_batching_matches_the_oracle(pkg, ctx, oracle):
+    # configs[2] in miniature: the engine mirror (prefill-first scheduling, max_num_seqs 3, post_process; scheduler.rs:106-249,
+    # llm_engine.rs:239-325) drives the HIP step; every request's completion must equal (a) the greedy continuation the
+    # CPU oracle produces for that request on its own and (b) what the request gets when it runs alone on the GPU
     from nano_vllm_candle_amd.engine import LLMEngine, Qwen3ModelRunner, SamplingParams, Scheduler, SchedulerConfig
 
     cfg = pkg.Qwen3Config.tiny()
@@ -206,19 +207,91 @@ def test_engine_continuous_batching_matches_single_sequence_runs(pkg, ctx):
     # the reference's prefill-first scheduler admits waiting sequences regardless of how many are running
     # (scheduler.rs:113-157 counts only the prefill batch), so the native pool needs a slot per admitted request
     m.kv_alloc(16, 8, 64)
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(2)
     rng = np.random.default_rng(3)
     prompts = [rng.integers(3, cfg.vocab_size, n).tolist() for n in (4, 30, 11, 2, 17)]
     sp = SamplingParams(max_tokens=6, ignore_eos=True)
 
     def run(ps, max_num_seqs):
         eng = LLMEngine(Scheduler(SchedulerConfig(max_num_seqs=max_num_seqs, eos=cfg.eos_token_id)),
-                        Qwen3ModelRunner(m, raise_errors=True))
+                        Qwen3ModelRunner(m, greedy=True, raise_errors=True))
         return [toks for _, toks in eng.generate(ps, sp)]
 
+    want = []
+    for p in prompts:  # the reference's loop for one request: re-feed the whole sequence, take the last max
+        seq = list(p)
+        for _ in range(sp.max_tokens):
+            nxt, _ = om.run_greedy([seq])
+            seq.append(int(nxt[0]))
+        want.append(seq[len(p):])
     batched = run(prompts, 3)
+    assert batched == want
     alone = [run([p], 1)[0] for p in prompts]
     assert batched == alone
     assert m.free_blocks() == 16  # every finished sequence released its blocks
+
+
+def _write_safetensors(path, tensors):
+    """minimal safetensors writer for the test's own files: 8-byte header length, JSON header, raw little-endian data"""
+    import json
+    import struct
+
+    header, blobs, off = {}, [], 0
+    for name, (dtype, arr) in tensors.items():
+        raw = np.ascontiguousarray(arr).tobytes()
+        header[name] = {"dtype": dtype, "shape": list(arr.shape), "data_offsets": [off, off + len(raw)]}
+        blobs.append(raw)
+        off += len(raw)
+    hj = json.dumps(header).encode()
+    hj += b" " * ((8 - len(hj) % 8) % 8)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(hj)))
+        f.write(hj)
+        for b in blobs:
+            f.write(b)
+
+
+@pytest.mark.parametrize("tied", [False, True])
+def test_sharded_bf16_checkpoint_from_hf_dir(pkg, ctx, oracle, tmp_path, tied):
+    # what Qwen3ForCausalLM::from_hf_dir loads (qwen3.rs:515-536, config parsing :77-101), in the form real checkpoints
+    # ship: bf16 tensors split over model-0000x-of-00002.safetensors + model.safetensors.index.json + config.json;
+    # tied = no lm_head.weight in the files (the LM head is the embedding table)
+    import json
+
+    cfg = pkg.Qwen3Config.tiny()
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(13)
+    names = list(cfg.hf_tensor_shapes().items())
+    if tied:
+        names = [(n, s) for n, s in names if n != "lm_head.weight"]
+        om.set_tensor("lm_head.weight", om.get_tensor("model.embed_tokens.weight", (cfg.vocab_size, cfg.hidden_size)))
+    files = {"model-00001-of-00002.safetensors": {}, "model-00002-of-00002.safetensors": {}}
+    weight_map = {}
+    for i, (n, shape) in enumerate(names):
+        f32 = om.get_tensor(n, shape)  # synthetic values are bf16-exact: the upper 16 bits are the whole number
+        bits = (f32.view(np.uint32) >> 16).astype(np.uint16)
+        assert np.array_equal((bits.astype(np.uint32) << 16).view(np.float32), f32)
+        fn = list(files)[i % 2]
+        files[fn][n] = ("BF16", bits)
+        weight_map[n] = fn
+    for fn, tensors in files.items():
+        _write_safetensors(tmp_path / fn, tensors)
+    (tmp_path / "model.safetensors.index.json").write_text(json.dumps({"metadata": {}, "weight_map": weight_map}))
+    (tmp_path / "config.json").write_text(json.dumps(dict(
+        vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, head_dim=cfg.head_dim, num_hidden_layers=cfg.num_hidden_layers,
+        num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads,
+        intermediate_size=cfg.intermediate_size, max_position_embeddings=cfg.max_position_embeddings,
+        rms_norm_eps=cfg.rms_norm_eps, hidden_act="silu", rope_theta=cfg.rope_theta, bos_token_id=cfg.bos_token_id,
+        eos_token_id=cfg.eos_token_id, tie_word_embeddings=tied)))
+    m = pkg.Qwen3ForCausalLM.from_hf_dir(str(tmp_path), ctx)
+    assert m.cfg == cfg
+    m.kv_alloc(4, 2, 64)
+    seqs = [[3, 1, 4, 1, 5, 9, 2, 6], [7, 7]]
+    for step in range(3):
+        ids, lg = m.step([0, 1], seqs, step == 0, want_logits=True)
+        rid, rlg = om.run_greedy(seqs)
+        assert row_rel_err(lg, rlg) < LOGITS_TOL and ids.tolist() == rid.tolist()
+        for s, t in zip(seqs, rid):
+            s.append(int(t))
 
 
 def test_qwen3_0_6b_shapes_vs_oracle(pkg, ctx, oracle):
