@@ -55,6 +55,11 @@ def parse():
     ap.add_argument("--tp-timeout", type=float, default=300.0)
     ap.add_argument("--force-device", type=int, default=-1, help="testing aid: every rank uses this GPU ordinal")
     ap.add_argument("--tp-leg-child", action="store_true", help=argparse.SUPPRESS)  # internal: run only the TP leg
+    ap.add_argument("--prefill-only", action="store_true",
+                    help="time the prefill of the batch (cold call + warmed repeats) and stop: the MFMA-side profile run")
+    ap.add_argument("--prefill-reps", type=int, default=3)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only (no GPU): every rank joins the gloo group, rank 0 prints the max rank seen")
     return ap.parse_args()
 
 
@@ -86,7 +91,7 @@ def cpu_baseline(cfg, prompts, n_seqs, seed):
     t0 = time.perf_counter()
     om.run_greedy(sample, all_rows=True, want_logits=False)
     dt = time.perf_counter() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", 0)) or len(os.sched_getaffinity(0))
+    cores = O.threads  # worker threads the oracle really used (CPU quota of the container, not visible cores)
     return {"value": n_seqs / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": f"1 engine step of {n_seqs} of the {len(prompts)} sequences (lens {[len(s) for s in sample]}), "
                       f"reference mode: no KV cache, full re-forward, LM head on all rows; {dt:.1f} s"}
@@ -137,6 +142,34 @@ def run_tp_extra(pkg, torch, dist, a, rank, world, local_rank):
     return res
 
 
+def spawn_ranks(n):
+    """Launcher for `python bench.py --gpus N` without torch.distributed.run: N child processes with
+    RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment, started BEFORE anything in this process initialises
+    the GPU (no exec of a GPU-initialised process anywhere).  Rank 0's stdout (the one JSON line) is relayed;
+    the exit code is non-zero when any rank fails."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -144,9 +177,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if a.force_device >= 0:
         local_rank = a.force_device
+    if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it never imports torch or touches a
+        # GPU) and starts one fresh rank process per GPU, exactly what torch.distributed.run would have started
+        sys.exit(spawn_ranks(a.gpus))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     import numpy as np
     import torch
 
@@ -159,6 +195,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane (id exchange, barrier, max over ranks) on gloo; the data path is RCCL inside the library
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    if a.launch_check:
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "world": world, "max_rank": int(t.item())}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     if a.tp_leg_child:
         # child process of a bench rank: only the tensor-parallel leg, result as one JSON line on stdout (rank 0)
@@ -195,8 +241,36 @@ def main():
     tp0 = time.perf_counter()
     model.step(seq_ids, prompts, is_prefill=True)
     torch.cuda.synchronize()
-    prefill_s = time.perf_counter() - tp0
+    prefill_cold_s = time.perf_counter() - tp0
     prefill_tokens = sum(len(p) for p in prompts)
+    # warmed figure: the same prefill again (is_prefill restarts the sequences and re-uses their blocks); the first call
+    # also pays one-time costs (kernel code upload, LDS-size attributes, first touch of the step buffers)
+    reps = a.prefill_reps if a.prefill_only else 1
+    tw = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        model.step(seq_ids, prompts, is_prefill=True)
+        torch.cuda.synchronize()
+        tw.append(time.perf_counter() - tp0)
+    prefill_s = min(tw)
+    mm_params = (model.weight_bytes * tpw) / 2
+    pf_tflops = 2.0 * mm_params * prefill_tokens / prefill_s / 1e12
+    # prefill is the MFMA-bound side: algorithmic flops = 2 * matmul params * tokens (attention excluded);
+    # the kernels issue 2x that on the MFMA pipe because activations are bf16 hi + lo (DESIGN.md 5)
+    prefill_info = {"tokens": prefill_tokens, "ms": prefill_s * 1e3, "ms_first_call": prefill_cold_s * 1e3,
+                    "tokens_per_s": prefill_tokens / prefill_s, "algorithmic_tflops": pf_tflops,
+                    "mfma_peak_tflops_bf16_dense": 2500.0 * tpw, "frac_of_mfma_peak": pf_tflops / (2500.0 * tpw),
+                    "note": "warmed (repeat of the same prefill); ms_first_call includes one-time setup"}
+    if a.prefill_only:
+        if rank == 0:
+            print(json.dumps({"metric": "prefill tokens/sec", "value": prefill_tokens / prefill_s, "unit": "tokens/s",
+                              "n_gpus": world, "config": {"workload": f"{a.model} prefill of {a.batch} prompts U[{a.prompt_min},{a.prompt_max}] seed {a.seed}"},
+                              "prefill": prefill_info}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     ctx_lens = np.array([len(p) + 1 for p in prompts], dtype=np.int64)  # tokens attended by the next decode step
 
     def barrier():
@@ -280,14 +354,15 @@ def main():
     launch_us = max(raw_us - bracket_us, 1e-3)  # bracketed duration minus the calibrated empty bracket
     roof = {"bound": "hbm", "kernel": dom_name, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "avg_launch_us": launch_us, "avg_launch_us_bracketed": raw_us, "bracket_correction_us": bracket_us}
-    # HBM bytes per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, gfx950 x2 correction applied):
-    # a separate profiled run of this same command, so it is quoted with that run's own algorithmic bytes
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_size.json")
-    if os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path)).get(dom_name)
+    # `traffic` (PMC HBM bytes of THIS run) needs rocprofv3 around the process, so it is null in the live line; the
+    # committed counter pass of the same command is quoted beside it with its own algorithmic bytes (a different run,
+    # hence a different context: never mixed into `achieved`)
+    for pmc_path in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_fetch_size.json")), reverse=True):
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_path))).get(dom_name)
         if pmc:
-            roof["traffic"] = pmc["fetch_bytes_per_launch"]
-            roof["traffic_run_algorithmic_bytes"] = pmc["algorithmic_bytes_per_launch"]
+            roof["traffic_from_profile"] = {"file": "profiles/" + pmc_path, "fetch_bytes_per_launch": pmc["fetch_bytes_per_launch"],
+                                            "algorithmic_bytes_per_launch": pmc["algorithmic_bytes_per_launch"]}
+            break
     if dom_bytes is not None:
         roof["achieved"] = dom_bytes / (launch_us * 1e-6) / 1e9
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
@@ -307,13 +382,7 @@ def main():
                           "event_ms_per_step": ev_ms / a.steps},
         "kernel_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
     }
-    # prefill is the MFMA-bound side: algorithmic flops = 2 * matmul params * tokens (attention excluded);
-    # the kernels issue 2x that on the MFMA pipe because activations are bf16 hi + lo (DESIGN.md 5)
-    mm_params = (model.weight_bytes * tpw) / 2
-    pf_tflops = 2.0 * mm_params * prefill_tokens / prefill_s / 1e12
-    out["prefill"] = {"tokens": prefill_tokens, "ms": prefill_s * 1e3, "tokens_per_s": prefill_tokens / prefill_s,
-                      "algorithmic_tflops": pf_tflops, "mfma_peak_tflops_bf16_dense": 2500.0 * tpw,
-                      "frac_of_mfma_peak": pf_tflops / (2500.0 * tpw), "note": "first call, includes one-time setup"}
+    out["prefill"] = prefill_info
     if rank == 0 and world == 1 and not a.no_cpu_baseline:  # reported at N=1 only (driver contract)
         out["cpu_baseline"] = cpu_baseline(cfg, prompts, a.cpu_seqs, a.seed)
     # ---- tensor-parallel leg, in a CHILD process per rank (own rendezvous port): an RCCL crash or a collective that

@@ -34,14 +34,44 @@ def build(force=False):
 
 
 _lib = None
+threads = 0  # worker threads the oracle's loops use (set when the library is loaded)
+
+
+def usable_cpus():
+    """CPUs this process may really use: the scheduler affinity capped by the cgroup CPU quota.  A GPU box shows every
+    host core (256) to a container that is allowed 16 CPUs' worth of time; one OpenMP thread per visible core then
+    spends its time being throttled."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = parts[0], int(parts[1])
+            else:
+                quota = parts[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+            if quota not in ("max", "-1") and period > 0:
+                n = min(n, max(1, -(-int(quota) // period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit() and int(env) > 0:
+        n = int(env)
+    return n
 
 
 def lib():
-    global _lib
+    global _lib, threads
     if _lib is None:
         if not os.path.exists(_SO):
             build()
         L = C.CDLL(_SO)
+        L.oq3_set_threads.restype = C.c_int
+        L.oq3_set_threads.argtypes = [C.c_int]
+        threads = L.oq3_set_threads(usable_cpus())
         fp, u32p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
         L.oq3_create.restype = C.c_void_p
         L.oq3_create.argtypes = [C.POINTER(Config)]

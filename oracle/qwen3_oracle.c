@@ -20,6 +20,7 @@
  * reference is tolerance-based (1e-3 relative on logits), never bit-exact.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -54,6 +55,13 @@ typedef struct {
     /* optional per-layer taps: (h, residual) returned by every decoder layer, qwen3.rs:398 */
     float *trace_h, *trace_res;
 } oq3_model;
+
+/* worker threads of every parallel loop below; returns the count in effect.  The caller sizes it to the CPUs it
+ * may really use (a container's cgroup quota can be far below the visible cores: oracle.py usable_cpus) */
+OQ3_API int oq3_set_threads(int n) {
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* ops                                                                                        */

@@ -294,12 +294,11 @@ def test_sharded_bf16_checkpoint_from_hf_dir(pkg, ctx, oracle, tmp_path, tied):
             s.append(int(t))
 
 
-def test_qwen3_0_6b_shapes_vs_oracle(pkg, ctx, oracle):
+def test_qwen3_0_6b_shapes_vs_oracle(pkg, ctx, oracle_0_6b):
     # configs[0]/[1] at the real shapes: 1 sequence, prompt 16, greedy steps (CPU oracle: full recompute each step)
-    cfg = pkg.Qwen3Config.qwen3_0_6b()
+    cfg, om = oracle_0_6b
     m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
     m.kv_alloc(4, 2, 256)
-    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(0)
     seq = [np.random.default_rng(0).integers(0, cfg.vocab_size, 16).tolist()]
     worst = 0.0
     for step in range(6):

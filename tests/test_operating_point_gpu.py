@@ -51,12 +51,6 @@ def oracle_rows(om, seqs):
     return np.array(ids), np.stack(lgs)
 
 
-@pytest.fixture(scope="module")
-def oracle_0_6b(pkg, oracle):
-    cfg = pkg.Qwen3Config.qwen3_0_6b()
-    return cfg, oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(0)
-
-
 def test_0_6b_full_depth_long_contexts_vs_oracle(pkg, ctx, oracle_0_6b):
     # configs[1]/[2] contexts on the full 28-layer model: 4 sequences with prompts {64, 292, 512, 511}, chunked
     # prefill (1379 rows through 512-row chunks) + 8 decode steps; f16 K/V + f16 P rounding grows with context and
@@ -234,4 +228,43 @@ def test_more_sequences_than_batched_tokens(pkg, ctx, oracle):
     with pytest.raises(pkg._lib.NvllmError) as e:
         m.decode_next()
     assert e.value.code == pkg._lib.ESTATE
+    m.close()
+
+
+def test_decode_execution_forms_agree_bit_for_bit(pkg, ctx, oracle):
+    # the decode step runs as one stream of launches, as row groups on their own streams (micro-batches of whole 16-row
+    # blocks: 40 rows -> 16 + 16 + 8) and as a replayed hipGraph of either; rows are independent through every layer,
+    # so all forms must produce the same ids bit for bit -- and the ids the oracle produces
+    cfg = pkg.Qwen3Config.tiny(vocab_size=8192, hidden_size=1024, head_dim=128, num_hidden_layers=2,
+                               num_attention_heads=16, num_key_value_heads=8, intermediate_size=3072)
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
+    m.kv_alloc(num_blocks=48, max_seqs=40, max_batched_tokens=2048)
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(0)
+    rng = np.random.default_rng(12)
+    sids = list(range(40))
+    prompts = [rng.integers(0, cfg.vocab_size, int(n)).tolist() for n in rng.integers(3, 71, 40)]
+    ref = None
+    for micro, graph in ((1, 0), (1, 1), (2, 1), (4, 0), (4, 1)):
+        m.set_decode_mode(micro, graph)
+        first, _ = m.step(sids, prompts, True)
+        got = [first[:40].copy()] + [m.decode_next()[:40].copy() for _ in range(5)]  # the graph is captured at the 2nd step
+        m.decode_enqueue()
+        for _ in range(3):  # pipelined form: one step ahead of the collected one
+            m.decode_enqueue()
+            got.append(m.decode_collect()[:40].copy())
+        got.append(m.decode_collect()[:40].copy())
+        if ref is None:
+            ref = got
+        else:
+            assert all(np.array_equal(x, y) for x, y in zip(ref, got)), (micro, graph)
+    m.set_decode_mode(-1, -1)
+    sample = [0, 17, 39]
+    seqs = [list(prompts[i]) for i in sample]
+    for step in range(4):
+        rid, rlg = om.run_greedy(seqs)
+        srt = np.sort(rlg, axis=1)
+        clear = (srt[:, -1] - srt[:, -2]) / np.abs(rlg).max(axis=1) > MARGIN
+        assert (ref[step][sample] == rid)[clear].all(), step
+        for s, t in zip(seqs, ref[step][sample]):
+            s.append(int(t))
     m.close()

@@ -120,3 +120,19 @@ def test_tp2_decomposition_matches_unsharded_layer():
     # summation order differs across ranks, so tolerance not bit-equality (SURVEY §7 hard parts)
     assert e_attn < 1e-5 and e_mlp < 1e-5, (e_attn, e_mlp)
     assert ids == ref_ids
+
+
+def test_bench_launches_its_own_ranks_from_a_plain_command():
+    # `python bench.py --gpus 2` with no torch.distributed.run around it: the launcher starts one rank process per GPU
+    # (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their env) and relays rank 0's single JSON line; --launch-check stops
+    # after the gloo rendezvous, so this runs without a GPU
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cp = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                        capture_output=True, text=True, timeout=240)
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"launch_check": True, "world": 2, "max_rank": 1}
