@@ -22,11 +22,6 @@ extern "C" {
  * While a kind is set every launch of that class is bracketed by two events; read returns the summed
  * elapsed ms and the number of launches since the last read. */
 int nvllm_profile_kernel(nvllm_model* m, int kind);
-/* A/B switch of the decode step's execution form (results are identical bit for bit in every form):
- * micro_groups = row groups of whole 16-row blocks that run the layer chain on their own streams (0/1 = one
- * stream, -1 = default / NVLLM_MICRO); use_graph = replay the step as a captured hipGraph (0 = eager launches,
- * -1 = default / NVLLM_GRAPH). */
-int nvllm_debug_set_decode_mode(nvllm_model* m, int micro_groups, int use_graph);
 int nvllm_profile_read(nvllm_model* m, double* total_ms, int64_t* launches);
 /* copy per-layer taps of the last step to the host (debug/parity): what = 0 layer output h,
  * 1 residual; [rows, hidden] f32 of layer `layer`; rows = rows of the last step's last chunk */

@@ -67,7 +67,6 @@ _SIGS = {
     "nvllm_decode_collect": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "nvllm_last_step_bytes": (C.c_int64, [_vp]),
     "nvllm_profile_kernel": (C.c_int, [_vp, C.c_int]),
-    "nvllm_debug_set_decode_mode": (C.c_int, [_vp, C.c_int, C.c_int]),
     "nvllm_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "nvllm_debug_layer_tap": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int64]),
     "nvllm_debug_enable_taps": (C.c_int, [_vp, C.c_int]),

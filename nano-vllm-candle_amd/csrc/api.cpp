@@ -275,7 +275,6 @@ static int dmalloc(nvllm_ctx* c, T** p, size_t count) {
 constexpr int kFusedMaxRows = 128;  // the fused decode path (deferred norms, row-parallel epilogues) handles up to this many rows
 constexpr int kMaxPending = 4;   // decode steps that may be enqueued before one is collected
 constexpr int kAttnMaxParts = 64;  // split-KV partitions per sequence (partition grows with context beyond 8K)
-constexpr int kMaxMicro = 4;       // decode micro-batches (row groups on their own streams); one HW queue each
 
 struct LayerW {
     PackedW qkv, o, gu, down;
@@ -342,17 +341,6 @@ struct nvllm_model {
     hipEvent_t pend_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<int> pending;
     int pend_next = 0;
-
-    // micro-batched decode (fused_micro_plan): row groups of micro_rows rows on their own streams
-    int micro_groups = 1, micro_rows = 0;
-    int opt_micro = -1, opt_graph = -1;  // nvllm_debug_set_decode_mode overrides (-1: environment / default)
-    hipStream_t mstream[kMaxMicro] = {nullptr, nullptr, nullptr, nullptr};  // [0] unused (group 0 runs on the main stream)
-    hipEvent_t ev_fork = nullptr, ev_join[kMaxMicro] = {nullptr, nullptr, nullptr, nullptr};
-    int* d_tile_order_g = nullptr;  // q-tile ranks sorted inside each micro-batch group (local indices)
-    // captured decode step (hipGraph): replayed while the batch geometry stays the same
-    hipGraphExec_t dec_graph = nullptr;
-    int dec_graph_key[6] = {0, 0, 0, 0, 0, 0};
-    int dec_graph_warm = 0;  // eager steps run with the current geometry (capture starts after one)
 
     // per-kernel-class HIP-event timing (bench roofline leg); 0 = off
     int prof_kind = 0;
@@ -453,13 +441,11 @@ static void free_kv(nvllm_model* m) {
     m->kcache.clear(); m->vcache.clear();
     void* ptrs[] = {m->d_block_tables, m->d_ids, m->d_pos, m->d_slot, m->d_tile_row0, m->d_tile_nrows, m->d_tile_slot,
                     m->d_last_rows, m->d_tile_order, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->xh2, m->xl2, m->ctxh, m->ctxl, m->ssqA, m->ssqB, m->d_next,
-                    m->part_val, m->part_idx, m->argmax_scratch, m->attn_po, m->attn_pml, m->tap_h, m->tap_res, m->cosv, m->sinv, m->d_tile_order_g};
+                    m->part_val, m->part_idx, m->argmax_scratch, m->attn_po, m->attn_pml, m->tap_h, m->tap_res, m->cosv, m->sinv};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     m->d_block_tables = nullptr; m->d_ids = nullptr; m->d_pos = m->d_slot = m->d_tile_row0 = m->d_tile_nrows = m->d_tile_slot = m->d_last_rows = m->d_tile_order = nullptr;
     m->resid = m->slabs = m->qbuf = m->logits = m->d_maxval = m->red = nullptr; m->xh = m->xl = m->xh2 = m->xl2 = m->ctxh = m->ctxl = nullptr; m->ssqA = m->ssqB = nullptr; m->d_next = nullptr; m->part_val = nullptr; m->part_idx = nullptr; m->argmax_scratch = nullptr; m->attn_po = m->attn_pml = nullptr;
-    m->tap_h = m->tap_res = nullptr; m->cosv = m->sinv = nullptr; m->d_tile_order_g = nullptr;
-    if (m->dec_graph) { (void)hipGraphExecDestroy(m->dec_graph); m->dec_graph = nullptr; }  // its nodes point into the freed buffers
-    m->dec_graph_warm = 0;
+    m->tap_h = m->tap_res = nullptr; m->cosv = m->sinv = nullptr;
     if (m->h_stage) (void)hipHostFree(m->h_stage);
     m->h_stage = nullptr;
     m->num_blocks = 0;
@@ -473,12 +459,6 @@ extern "C" int nvllm_model_destroy(nvllm_model* m) {
     if (m->pin_ids) (void)hipHostFree(m->pin_ids);
     for (hipEvent_t e : m->pend_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
-    for (int g = 1; g < kMaxMicro; ++g) {
-        if (m->mstream[g]) (void)hipStreamSynchronize(m->mstream[g]);
-        if (m->ev_join[g]) (void)hipEventDestroy(m->ev_join[g]);
-        if (m->mstream[g]) (void)hipStreamDestroy(m->mstream[g]);
-    }
-    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     (void)hipFree(m->embed); (void)hipFree(m->lm_head.data); (void)hipFree(m->norm);
     for (auto& w : m->layers) {
         (void)hipFree(w.qkv.data); (void)hipFree(w.o.data); (void)hipFree(w.gu.data); (void)hipFree(w.down.data);
@@ -729,7 +709,6 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->d_tile_slot, R);
     if (!rc) rc = dmalloc(ctx, &m->d_last_rows, (size_t)max_seqs);
     if (!rc) rc = dmalloc(ctx, &m->d_tile_order, R);
-    if (!rc) rc = dmalloc(ctx, &m->d_tile_order_g, R);
     if (!rc) rc = dmalloc(ctx, &m->resid, R * m->H);
     if (!rc) rc = dmalloc(ctx, &m->slabs, m->slab_floats);
     if (!rc) rc = dmalloc(ctx, &m->qbuf, R * m->nh_l * m->hd);
@@ -765,7 +744,7 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->argmax_scratch, (size_t)max_seqs + 1);
     if (!rc) HIPCHK(ctx, hipMemsetAsync(m->argmax_scratch, 0, ((size_t)max_seqs + 1) * 8, ctx->stream));
     if (rc) return rc;
-    m->h_stage_bytes = (R * 8 + (size_t)max_seqs * 4) * sizeof(int) + 256;
+    m->h_stage_bytes = (R * 7 + (size_t)max_seqs * 4) * sizeof(int) + 256;
     HIPCHK(ctx, hipHostMalloc(&m->h_stage, m->h_stage_bytes, hipHostMallocDefault));
     // RoPE table: rotary_embedding.rs:56-80 (f32: inv_freq = 1/base^(2j/hd); angle = pos * inv_freq)
     m->rope_len = std::min(m->cfg.max_position_embeddings, m->max_blocks * kBlockTokens);
@@ -859,19 +838,14 @@ static int tp_reduce(nvllm_model* m, int rows, int ns, const float** in, int* n_
 // The two RMSNorm launches per layer disappear: the row-parallel epilogue writes x' = w_next (.) resid and
 // the row's partial sums of squares; every consumer multiplies its (linear) result by rinv[row] (RowNorm).
 // ---------------------------------------------------------------------------------------------------
-// One group of rows [r0, r0 + R) of the chunk on stream s: layer-0 input prep + all layers.  Every buffer of the
-// step is indexed by row, so a group works on base pointers advanced by r0 rows (r0 % 16 == 0: packed planes are
-// stored per 16-row block, and a row block of a packed [rows][K] plane starts at element r0*K like a row-major one).
-// The kernels see local rows 0..R-1.  tile_order: this group's q-tile ranks (local tile indices).
-static int fused_layers(nvllm_model* m, int r0, int R, int n_tiles, int qt, const int* tile_order, hipStream_t s) {
+static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n_last, int logits_row0) {
+    nvllm_ctx* ctx = m->ctx;
+    hipStream_t s = ctx->stream;
     const int H = m->H, hd = m->hd;
     const float eps = (float)m->cfg.rms_norm_eps;
     const int NQ = (m->nh_l + 2 * m->kv_l) * hd;
     const int KO = m->nh_l * hd;
-    const size_t o = (size_t)r0;
-    bf16_bits *xh = m->xh + o * H, *xl = m->xl + o * H, *ctxh = m->ctxh + o * KO, *ctxl = m->ctxl + o * KO;
-    bf16_bits *xh2 = m->xh2 + o * m->I_l, *xl2 = m->xl2 + o * m->I_l;
-    float *resid = m->resid + o * H, *qkv = m->slabs + o * NQ, *ssqA = m->ssqA + o, *ssqB = m->ssqB + o;
+    m->tap_rows = R;
     RowNorm rn;  // the norm pending on xh/xl
     rn.stride = kFusedMaxRows; rn.inv_h = 1.0f / (float)H; rn.eps = eps;
     // every GEMM of the layer on the register-direct kernel: the activation planes stay in fragment order
@@ -880,148 +854,90 @@ static int fused_layers(nvllm_model* m, int r0, int R, int n_tiles, int qt, cons
                        gemm_rowdir_ok(2 * m->I_l, H, 1, R) && gemm_rowdir_ok(H, m->I_l, 0, R);
     {   // layer 0 input: residual = embedding row, x' = ln1 (.) row, ssq (qwen3.rs:382-386, 465-468)
         NormArgs na;
-        na.ids = m->d_ids + o; na.embed = m->embed; na.weight = m->layers[0].ln1; na.eps = eps; na.H = H;
-        na.xh = xh; na.xl = xl; na.residual_out = resid; na.ssq_out = ssqB; na.out_packed = packed;
+        na.ids = m->d_ids; na.embed = m->embed; na.weight = m->layers[0].ln1; na.eps = eps; na.H = H;
+        na.xh = m->xh; na.xl = m->xl; na.residual_out = m->resid; na.ssq_out = m->ssqB; na.out_packed = packed;
         PROF(m, PROF_NORM, launch_add_rmsnorm(na, R, s));
-        rn.ssq = ssqB; rn.groups = 1;
+        rn.ssq = m->ssqB; rn.groups = 1;
     }
     for (int l = 0; l < m->L; ++l) {
         const LayerW& w = m->layers[l];
         QkvArgs qa;
         {   // QKV projection: whole-K row-parallel kernel (one f32 result, no slabs) when the shape allows
             RowParArgs rq;
-            rq.xh = xh; rq.xl = xl; rq.ldx = H; rq.out = qkv; rq.M = R; rq.x_packed = packed;
+            rq.xh = m->xh; rq.xl = m->xl; rq.ldx = H; rq.out = m->slabs; rq.M = R; rq.x_packed = packed;
             if (gemm_rowpar_ok(NQ, H, 2, R)) {
                 PROF(m, PROF_GEMM, launch_gemm_rowpar(rq, w.qkv, 2, s));
                 qa.n_slabs = 1;
             } else {
                 GemmPlan pq = plan_gemm(R, NQ, H, 8);
-                PROF(m, PROF_GEMM, launch_gemm(pq, xh, xl, H, w.qkv, qkv, R, s));
+                PROF(m, PROF_GEMM, launch_gemm(pq, m->xh, m->xl, H, w.qkv, m->slabs, R, s));
                 qa.n_slabs = pq.n_split;
             }
         }
-        qa.qkv = qkv; qa.slab_stride = (int64_t)R * NQ; qa.qn = w.qn; qa.kn = w.kn; qa.eps = eps;
-        qa.cos = m->cosv; qa.sin = m->sinv; qa.pos = m->d_pos + o; qa.slot = m->d_slot + o; qa.block_tables = m->d_block_tables;
+        qa.qkv = m->slabs; qa.slab_stride = (int64_t)R * NQ; qa.qn = w.qn; qa.kn = w.kn; qa.eps = eps;
+        qa.cos = m->cosv; qa.sin = m->sinv; qa.pos = m->d_pos; qa.slot = m->d_slot; qa.block_tables = m->d_block_tables;
         qa.max_blocks = m->max_blocks; qa.nh_l = m->nh_l;
         qa.q_scale = powf((float)hd, -0.5f) * 1.4426950408889634f;
-        qa.q_out = m->qbuf + o * KO; qa.rn = rn;
+        qa.q_out = m->qbuf; qa.rn = rn;
         qa.kv.k = m->kcache[l]; qa.kv.v = m->vcache[l]; qa.kv.kv_l = m->kv_l; qa.kv.hd = hd;
         const bool fuse_qk = qt == 1 && n_tiles == R;
         if (!fuse_qk) PROF(m, PROF_QK, launch_qk_norm_rope_kvwrite(qa, R, s));
         AttnArgs aa;
-        aa.q = qa.q_out; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
-        aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot + (fuse_qk ? o : 0); aa.pos = m->d_pos + o;
-        aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = ctxh; aa.out_lo = ctxl; aa.out_packed = packed;
-        if (qt == 1) aa.tile_order = tile_order;
+        aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
+        aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
+        aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->ctxh; aa.out_lo = m->ctxl; aa.out_packed = packed;
+        if (qt == 1) aa.tile_order = m->d_tile_order;
         if (fuse_qk) {
             aa.qkv = qa.qkv; aa.n_slabs = qa.n_slabs; aa.slab_stride = qa.slab_stride; aa.ldqkv = NQ; aa.qn = w.qn; aa.kn = w.kn;
             aa.cos = m->cosv; aa.sin = m->sinv; aa.eps = eps; aa.q_scale = qa.q_scale; aa.rn = rn;
         }
         int parts_max = 1;
         if (qt == 1 && R <= m->max_seqs) {
-            aa.part_tiles = m->attn_part_tiles; aa.max_parts = kAttnMaxParts;
-            aa.part_o = m->attn_po + o * m->nh_l * kAttnMaxParts * hd; aa.part_ml = m->attn_pml + o * m->nh_l * kAttnMaxParts * 2;
+            aa.part_tiles = m->attn_part_tiles; aa.max_parts = kAttnMaxParts; aa.part_o = m->attn_po; aa.part_ml = m->attn_pml;
             parts_max = m->attn_parts_max;
         }
         PROF(m, PROF_EMPTY, hipSuccess);  // calibration: an event pair around nothing, at the attention launch's place
         PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
         // o_proj + residual + post-attention norm prep (qwen3.rs:278, :393)
         RowParArgs ra;
-        ra.xh = ctxh; ra.xl = ctxl; ra.ldx = KO; ra.resid_in = resid; ra.resid_out = resid; ra.next_w = w.ln2;
-        ra.oh = xh; ra.ol = xl; ra.ssq = ssqA; ra.ssq_stride = kFusedMaxRows; ra.M = R;
+        ra.xh = m->ctxh; ra.xl = m->ctxl; ra.ldx = KO; ra.resid_in = m->resid; ra.resid_out = m->resid; ra.next_w = w.ln2;
+        ra.oh = m->xh; ra.ol = m->xl; ra.ssq = m->ssqA; ra.ssq_stride = kFusedMaxRows; ra.M = R;
         ra.x_packed = packed; ra.o_packed = packed;
         PROF(m, PROF_GEMM, launch_gemm_rowpar(ra, w.o, 0, s));
-        rn.ssq = ssqA; rn.groups = gemm_rowpar_groups(H, KO);
+        rn.ssq = m->ssqA; rn.groups = gemm_rowpar_groups(H, KO);
         // gate/up + SiLU*mul (qwen3.rs:324-325), scaled by the pending norm's rinv
         {
             RowParArgs rg;
-            rg.xh = xh; rg.xl = xl; rg.ldx = H; rg.oh = xh2; rg.ol = xl2; rg.M = R; rg.rn = rn;
+            rg.xh = m->xh; rg.xl = m->xl; rg.ldx = H; rg.oh = m->xh2; rg.ol = m->xl2; rg.M = R; rg.rn = rn;
             rg.x_packed = packed; rg.o_packed = packed;
             if (gemm_rowpar_ok(2 * m->I_l, H, 1, R)) {
                 PROF(m, PROF_GEMM, launch_gemm_rowpar(rg, w.gu, 1, s));
             } else {
                 GemmPlan pg = plan_gemm_swiglu(R, 2 * m->I_l, H);
-                PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, xh, xl, H, w.gu, R, xh2, xl2, &rn, s));
+                PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, &rn, s));
             }
         }
         // down_proj + residual + next layer's input norm prep (qwen3.rs:326, next layer :378; last layer: final norm :497)
         RowParArgs rd;
-        rd.xh = xh2; rd.xl = xl2; rd.ldx = m->I_l; rd.resid_in = resid; rd.resid_out = resid;
+        rd.xh = m->xh2; rd.xl = m->xl2; rd.ldx = m->I_l; rd.resid_in = m->resid; rd.resid_out = m->resid;
         rd.next_w = l + 1 < m->L ? m->layers[l + 1].ln1 : m->norm;
-        rd.oh = xh; rd.ol = xl; rd.ssq = ssqB; rd.ssq_stride = kFusedMaxRows; rd.M = R;
+        rd.oh = m->xh; rd.ol = m->xl; rd.ssq = m->ssqB; rd.ssq_stride = kFusedMaxRows; rd.M = R;
         rd.x_packed = packed; rd.o_packed = packed && l + 1 < m->L;  // the LM head (chunked kernel) reads row-major planes
         PROF(m, PROF_GEMM, launch_gemm_rowpar(rd, w.down, 0, s));
-        rn.ssq = ssqB; rn.groups = gemm_rowpar_groups(H, m->I_l);
+        rn.ssq = m->ssqB; rn.groups = gemm_rowpar_groups(H, m->I_l);
     }
-    return NVLLM_OK;
-}
-
-// LM head on the last-token rows only (gathered by row_idx), logits scaled by the final norm's rinv; greedy ids
-static int fused_head(nvllm_model* m, int n_last, int logits_row0, hipStream_t s) {
-    nvllm_ctx* ctx = m->ctx;
-    const int H = m->H;
-    RowNorm rn;
-    rn.stride = kFusedMaxRows; rn.inv_h = 1.0f / (float)H; rn.eps = (float)m->cfg.rms_norm_eps;
-    rn.ssq = m->ssqB; rn.groups = gemm_rowpar_groups(H, m->I_l);
-    GemmPlan pl = plan_lmhead(n_last, m->V_l, H);
-    float* lg = m->want_logits ? m->logits + (size_t)logits_row0 * m->V_l : nullptr;
-    rn.row_idx = m->d_last_rows;
-    PROF(m, PROF_LMHEAD, launch_gemm_argmax(pl, m->xh, m->xl, H, m->lm_head, lg, n_last, m->part_val, m->part_idx, &rn, s));
-    if (pl.lm_nt > 0)
-        HIPCHK(ctx, launch_argmax_rows(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, m->d_next + logits_row0, nullptr, s));
-    else
-        HIPCHK(ctx, launch_argmax_parts(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, m->argmax_scratch,
-                                        m->d_next + logits_row0, nullptr, s));
-    return NVLLM_OK;
-}
-
-// Micro-batched decode: the rows of a decode step are independent through every layer, so they are cut into groups of
-// whole 16-row blocks that run the layer chain on their own streams.  A single chain is bound by dependent latency
-// (launch boundary + one HBM/L2 round trip per kernel); with several chains in flight one group's
-// attention streams KV while another group's small GEMMs wait on their loads.  The weights of a layer are read by every
-// group: only worth it while a layer's matrices fit the caches several times over.  Groups join before the LM head
-// (the vocabulary matrix is streamed once for all rows).
-static int fused_micro_plan(const nvllm_model* m, int R, int qt, int n_tiles) {
-    static const int env_micro = [] { const char* e = getenv("NVLLM_MICRO"); return e ? atoi(e) : -1; }();
-    const int env = m->opt_micro >= 0 ? m->opt_micro : env_micro;
-    if (env == 0 || env == 1 || qt != 1 || n_tiles != R || m->attn_parts_max > 1 || R < 32) return 1;
-    size_t layer_bytes = 0;
-    if (!m->layers.empty()) { const LayerW& w = m->layers[0]; layer_bytes = w.qkv.bytes() + w.o.bytes() + w.gu.bytes() + w.down.bytes(); }
-    if (layer_bytes > ((size_t)48 << 20)) return 1;
-    // groups share the QKV result buffer by rows: only the whole-K kernels (one complete f32 result, no split-K slabs)
-    const int NQ = (m->nh_l + 2 * m->kv_l) * m->hd;
-    if (!gemm_rowpar_ok(NQ, m->H, 2, 16) || gemm_rowpar_splits(NQ, m->H, 2, 16) != 1 || !gemm_rowpar_ok(2 * m->I_l, m->H, 1, 16)) return 1;
-    const int blocks = (R + 15) / 16;
-    int want = env > 1 ? env : 4;
-    return std::max(1, std::min({want, kMaxMicro, blocks}));
-}
-
-static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n_last, int logits_row0) {
-    nvllm_ctx* ctx = m->ctx;
-    hipStream_t s = ctx->stream;
-    m->tap_rows = R;
-    // per-kernel profiling brackets every launch with events on the main stream: single-stream path
-    const int nm = m->micro_groups > 1 && qt == 1 && n_tiles == R && !m->prof_kind ? m->micro_groups : 1;
-    if (nm <= 1) {
-        int rc = fused_layers(m, 0, R, n_tiles, qt, m->d_tile_order, s);
-        if (rc) return rc;
-    } else {
-        // fork: every group stream waits for what the main stream has queued so far (ids/pos of this step)
-        HIPCHK(ctx, hipEventRecord(m->ev_fork, s));
-        for (int g = 0; g < nm; ++g) {
-            const int r0 = g * m->micro_rows, rg = std::min(m->micro_rows, R - r0);
-            if (rg <= 0) break;
-            hipStream_t sg = g == 0 ? s : m->mstream[g];
-            if (g) HIPCHK(ctx, hipStreamWaitEvent(sg, m->ev_fork, 0));
-            int rc = fused_layers(m, r0, rg, rg, 1, m->d_tile_order_g + r0, sg);
-            if (rc) return rc;
-            if (g) {
-                HIPCHK(ctx, hipEventRecord(m->ev_join[g], sg));
-                HIPCHK(ctx, hipStreamWaitEvent(s, m->ev_join[g], 0));
-            }
-        }
+    if (n_last > 0) {
+        // LM head on the last-token rows only (gathered by row_idx), logits scaled by the final norm's rinv
+        GemmPlan pl = plan_lmhead(n_last, m->V_l, H);
+        float* lg = m->want_logits ? m->logits + (size_t)logits_row0 * m->V_l : nullptr;
+        rn.row_idx = m->d_last_rows;
+        PROF(m, PROF_LMHEAD, launch_gemm_argmax(pl, m->xh, m->xl, H, m->lm_head, lg, n_last, m->part_val, m->part_idx, &rn, s));
+        if (pl.lm_nt > 0)
+            HIPCHK(ctx, launch_argmax_rows(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, m->d_next + logits_row0, nullptr, s));
+        else
+            HIPCHK(ctx, launch_argmax_parts(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, m->argmax_scratch,
+                                            m->d_next + logits_row0, nullptr, s));
     }
-    if (n_last > 0) return fused_head(m, n_last, logits_row0, s);
     return NVLLM_OK;
 }
 
@@ -1254,23 +1170,6 @@ static int finish_logits(nvllm_model* m, int n, uint32_t* next_ids, float* last_
     return NVLLM_OK;
 }
 
-// choose the micro-batch geometry of a decode step of R single-row tiles (1 group = the plain single-stream path)
-static int set_micro(nvllm_model* m, int R, int qt, int n_tiles) {
-    nvllm_ctx* ctx = m->ctx;
-    const int g = m->fused_ok && R <= kFusedMaxRows && !m->taps ? fused_micro_plan(m, R, qt, n_tiles) : 1;
-    m->micro_groups = g;
-    m->micro_rows = g > 1 ? (((R + g - 1) / g + 15) / 16) * 16 : R;
-    if (g > 1) m->micro_groups = (R + m->micro_rows - 1) / m->micro_rows;
-    if (m->micro_groups > 1 && !m->ev_fork) {
-        HIPCHK(ctx, hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-        for (int i = 1; i < kMaxMicro; ++i) {
-            HIPCHK(ctx, hipStreamCreateWithFlags(&m->mstream[i], hipStreamNonBlocking));
-            HIPCHK(ctx, hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
-        }
-    }
-    return NVLLM_OK;
-}
-
 struct RowPlan {
     std::vector<uint32_t> ids;
     std::vector<int> pos, slot, tile_row0, tile_nrows, tile_slot, last_rows;
@@ -1298,18 +1197,6 @@ static int upload_chunk(nvllm_model* m, const RowPlan& p, int r0, int R, int t0,
             return p.pos[p.tile_row0[t0 + x] + p.tile_nrows[t0 + x] - 1] > p.pos[p.tile_row0[t0 + y] + p.tile_nrows[t0 + y] - 1];
         });
         for (int i = 0; i < T; ++i) h_ord[i] = ord[i];
-    }
-    // the same ranking inside every micro-batch group (local tile indices), for the groups' own attention launches
-    int* h_ord_g = h_ord + T;
-    if (m->micro_groups > 1) {
-        for (int g0 = 0; g0 < T; g0 += m->micro_rows) {
-            const int n = std::min(m->micro_rows, T - g0);
-            std::vector<int> ord(n);
-            for (int i = 0; i < n; ++i) ord[i] = i;
-            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return p.pos[r0 + g0 + x] > p.pos[r0 + g0 + y]; });
-            for (int i = 0; i < n; ++i) h_ord_g[g0 + i] = ord[i];
-        }
-        HIPCHK(ctx, hipMemcpyAsync(m->d_tile_order_g, h_ord_g, (size_t)T * 4, hipMemcpyHostToDevice, s));
     }
     HIPCHK(ctx, hipMemcpyAsync(m->d_ids, h_ids, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(m->d_pos, h_pos, (size_t)R * 4, hipMemcpyHostToDevice, s));
@@ -1401,8 +1288,7 @@ extern "C" int nvllm_step(nvllm_model* m, int n_seqs, const int64_t* seq_ids, co
         std::vector<int> last_local;
         for (int i = 0; i < n_seqs; ++i)
             if (seq_last_row[i] >= r0 && seq_last_row[i] < r0 + R) last_local.push_back(seq_last_row[i] - r0);
-        int rc = set_micro(m, R, total_rows <= m->max_rows ? qt : 2, (int)p.tile_row0.size());
-        if (!rc) rc = upload_chunk(m, p, r0, R, 0, (int)p.tile_row0.size(), last_local);
+        int rc = upload_chunk(m, p, r0, R, 0, (int)p.tile_row0.size(), last_local);
         if (rc) return rc;
         rc = forward_chunk(m, R, (int)p.tile_row0.size(), qt, (int)last_local.size(), logits_row);
         if (rc) return rc;
@@ -1442,72 +1328,29 @@ static int decode_core(nvllm_model* m) {
     }
     if (table_dirty)
         HIPCHK(ctx, hipMemcpyAsync(m->d_block_tables, m->h_block_tables.data(), m->h_block_tables.size() * 4, hipMemcpyHostToDevice, s));
+    if (m->decode_resident) {
+        // ids <- last greedy ids, pos += 1: the batch metadata is already on the device
+        HIPCHK(ctx, launch_advance_decode(m->d_ids, m->d_next, m->d_pos, n, s));
+    } else {
+        // previous step was a prefill (or a multi-chunk step): rebuild decode metadata once
+        RowPlan p;
+        std::vector<int> last_local(n);
+        for (int i = 0; i < n; ++i) {
+            const SeqState& st = m->seqs[m->last_ids[i]];
+            p.ids.push_back(0); p.pos.push_back(m->last_lens[i]); p.slot.push_back(st.slot);
+            p.tile_row0.push_back(i); p.tile_nrows.push_back(1); p.tile_slot.push_back(st.slot);
+            last_local[i] = i;
+        }
+        int rc0 = upload_chunk(m, p, 0, n, 0, n, last_local);
+        if (rc0) return rc0;
+        HIPCHK(ctx, hipMemcpyAsync(m->d_ids, m->d_next, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        m->decode_resident = true;
+    }
     m->want_logits = false;
     m->cur_n = n;
     set_attn_split(m, n, *std::max_element(m->last_lens.begin(), m->last_lens.end()) + 1);
-    {   // micro-batch geometry of this step; the per-group tile orders on the device belong to the geometry they were
-        // uploaded with, so a change rebuilds the metadata
-        const int g0 = m->micro_groups, r0 = m->micro_rows;
-        int rcm = set_micro(m, n, 1, n);
-        if (rcm) return rcm;
-        if (m->micro_groups != g0 || m->micro_rows != r0) m->decode_resident = false;
-    }
-    // One decode step = ~150 (x micro-batch groups) dependent launches whose arguments only change when the batch
-    // geometry does: after one eager step with a geometry the step is captured into a hipGraph (fork/join of the
-    // group streams included) and replayed.  Host cost per step drops from one enqueue per kernel to one graph launch,
-    // which is what lets several group streams stay busy at once.
-    static const bool env_graph = [] { const char* e = getenv("NVLLM_GRAPH"); return !e || atoi(e) != 0; }();
-    const bool use_graph = m->opt_graph >= 0 ? m->opt_graph != 0 : env_graph;
-    const int key[6] = {n, m->micro_groups, m->micro_rows, m->attn_parts_max > 1 ? m->attn_part_tiles : 0, m->attn_parts_max, 1};
-    const bool graph_ok = use_graph && m->decode_resident && m->fused_ok && n <= kFusedMaxRows && !m->taps && !m->prof_kind &&
-                          ctx->tp_size == 1 && !getenv("NVLLM_NO_FUSED");
-    const bool key_same = !memcmp(key, m->dec_graph_key, sizeof key);
-    if (!key_same) {
-        if (m->dec_graph) { (void)hipGraphExecDestroy(m->dec_graph); m->dec_graph = nullptr; }
-        memcpy(m->dec_graph_key, key, sizeof key);
-        m->dec_graph_warm = 0;
-    }
-    int rc = NVLLM_OK;
-    if (graph_ok && (m->dec_graph || m->dec_graph_warm)) {
-        if (!m->dec_graph) {
-            HIPCHK(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            hipError_t e = launch_advance_decode(m->d_ids, m->d_next, m->d_pos, n, s);
-            if (e == hipSuccess) rc = forward_chunk(m, n, n, 1, n, 0);
-            hipGraph_t graph = nullptr;
-            const hipError_t e2 = hipStreamEndCapture(s, &graph);
-            if (e != hipSuccess || rc || e2 != hipSuccess) {
-                if (graph) (void)hipGraphDestroy(graph);
-                if (rc) return rc;
-                return fail(ctx, NVLLM_EHIP, "decode graph capture -> %s", hipGetErrorString(e != hipSuccess ? e : e2));
-            }
-            const hipError_t e3 = hipGraphInstantiate(&m->dec_graph, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (e3 != hipSuccess) { m->dec_graph = nullptr; return fail(ctx, NVLLM_EHIP, "hipGraphInstantiate -> %s", hipGetErrorString(e3)); }
-        }
-        HIPCHK(ctx, hipGraphLaunch(m->dec_graph, s));
-    } else {
-        if (m->decode_resident) {
-            // ids <- last greedy ids, pos += 1: the batch metadata is already on the device
-            HIPCHK(ctx, launch_advance_decode(m->d_ids, m->d_next, m->d_pos, n, s));
-        } else {
-            // previous step was a prefill (or a multi-chunk step): rebuild decode metadata once
-            RowPlan p;
-            std::vector<int> last_local(n);
-            for (int i = 0; i < n; ++i) {
-                const SeqState& st = m->seqs[m->last_ids[i]];
-                p.ids.push_back(0); p.pos.push_back(m->last_lens[i]); p.slot.push_back(st.slot);
-                p.tile_row0.push_back(i); p.tile_nrows.push_back(1); p.tile_slot.push_back(st.slot);
-                last_local[i] = i;
-            }
-            int rc0 = upload_chunk(m, p, 0, n, 0, n, last_local);
-            if (rc0) return rc0;
-            HIPCHK(ctx, hipMemcpyAsync(m->d_ids, m->d_next, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
-            m->decode_resident = true;
-        }
-        rc = forward_chunk(m, n, n, 1, n, 0);
-        if (rc) return rc;
-        if (!m->prof_kind) m->dec_graph_warm = 1;
-    }
+    int rc = forward_chunk(m, n, n, 1, n, 0);
+    if (rc) return rc;
     int64_t kv_tokens = 0;
     for (int i = 0; i < n; ++i) {
         m->last_lens[i] += 1;
@@ -1567,15 +1410,6 @@ extern "C" int nvllm_decode_collect(nvllm_model* m, uint32_t* next_ids) {
 }
 
 extern "C" int64_t nvllm_last_step_bytes(const nvllm_model* m) { return m ? m->last_bytes : 0; }
-
-extern "C" int nvllm_debug_set_decode_mode(nvllm_model* m, int micro_groups, int use_graph) {
-    if (!m || micro_groups > kMaxMicro) return NVLLM_EINVAL;
-    HIPCHK(m->ctx, hipStreamSynchronize(m->ctx->stream));
-    m->opt_micro = micro_groups;
-    m->opt_graph = use_graph;
-    m->decode_resident = false;  // the next decode step rebuilds its metadata for the new geometry
-    return NVLLM_OK;
-}
 
 extern "C" int nvllm_profile_kernel(nvllm_model* m, int kind) {
     if (!m || kind < 0 || kind > PROF_EMPTY) return NVLLM_EINVAL;

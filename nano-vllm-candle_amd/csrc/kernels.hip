@@ -230,6 +230,17 @@ hipError_t launch_split_hilo(const float* x, bf16_bits* hi, bf16_bits* lo, int64
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Barrier that PUBLISHES LDS-DMA data (global_load_lds): every wave first waits for its own DMA to land, then joins the
+// barrier; only then may any wave ds_read fragments another wave staged.  __syncthreads() alone is not enough: hipcc
+// (ROCm 7.2) emitted the loop-header barrier of gemm_kernel's chunk loop as `s_waitcnt lgkmcnt(0); s_barrier` with
+// the vmcnt(0) AFTER the barrier -- each wave then waits for its own DMA only, and reads of another wave's still-in-
+// flight fragments returned old LDS bytes (no stall, no fault): wrong sums under memory load (several contexts on one
+// GPU), clean on a quiet chip.  The asm wait is invisible to the compiler's waitcnt pass and cannot be moved.
+__device__ __forceinline__ void dma_publish_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // MODE 0: f32 slabs.  MODE 1: + per-wave partial arg-max (LM head).  MODE 2: SwiGLU epilogue -- the weight is
 // the gate/up matrix interleaved in 16-row tiles (NT == 2: tile 0 = gate, tile 1 = up of the same 16 features),
 // the wave writes silu(gate)*up as bf16 hi/lo planes act[M][N/2] (SiluAndMul, activation.rs:13-18); no split-K.
@@ -324,7 +335,7 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
         if (nchunks > 1) issue(1, 1, wf1);
         // deferred-norm partials: loaded AFTER the main loads were issued (vmcnt is in order), parked in LDS
         if constexpr (MODE != 0) rownorm_partials<MT * 16>(rn, m0, M, lds_rn);
-        __syncthreads();  // vmcnt(0) + barrier: everything has landed
+        dma_publish_barrier();  // vmcnt(0) + barrier: everything has landed
         if (nchunks > 0) compute(0, wf0);
         if (nchunks > 1) compute(1, wf1);
     } else {
@@ -332,11 +343,11 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
         issue(0, 0, wf0);
         if constexpr (MODE != 0) rownorm_partials<MT * 16>(rn, m0, M, lds_rn);
         for (int c = 0; c < nchunks; c += 2) {
-            __syncthreads();  // chunk c has landed; buffer 1 is free again
+            dma_publish_barrier();  // chunk c has landed; buffer 1 is free again
             if (c + 1 < nchunks) issue(c + 1, 1, wf1);
             compute(0, wf0);
             if (c + 1 >= nchunks) break;
-            __syncthreads();
+            dma_publish_barrier();
             if (c + 2 < nchunks) issue(c + 2, 0, wf0);
             compute(1, wf1);
         }
@@ -650,7 +661,7 @@ __global__ void __launch_bounds__(512) lmhead_kernel(const uint16_t* __restrict_
         // chunk c is in LDS and every wave is done with the other buffer.  After the first chunk the wait covers
         // only this wave's x stage: the KC/SC weight sets issued after it (vmcnt retires in order) stay in flight
         // across the barrier instead of draining the stream four times per launch.
-        if (c == 0) __syncthreads();
+        if (c == 0) dma_publish_barrier();
         else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((KC / SC) * NT * SC) : "memory");
         if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);  // the weight loads below are issued AFTER the stage (the count above relies on it)
@@ -854,7 +865,7 @@ __global__ void __launch_bounds__(512) gemm_stream_kernel(const uint16_t* __rest
     for (int c = 0; c < nchunks; ++c) {
         // as lmhead_kernel: after the first chunk only this wave's x stage is waited for, the KC/SC weight sets issued
         // after it stay in flight across the barrier
-        if (c == 0) __syncthreads();
+        if (c == 0) dma_publish_barrier();
         else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((KC / SC) * NT * SC) : "memory");
         if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -1100,7 +1111,7 @@ __global__ void __launch_bounds__(NWN * NWK * 64) gemm_rowpar_kernel(RowParArgs 
         }
     }
     if constexpr (EPI == 1) rownorm_partials<NR>(a.rn, m0, M, sred);
-    __syncthreads();
+    dma_publish_barrier();
 #pragma unroll
     for (int p = 0; p < PH; ++p) {
         compute(w[p], p & 1);
@@ -1108,7 +1119,7 @@ __global__ void __launch_bounds__(NWN * NWK * 64) gemm_rowpar_kernel(RowParArgs 
             __syncthreads();  // WAR: all waves are done with buffer p&1
             stage(p + 2, p & 1);
         }
-        if (p + 1 < PH && p >= 1) __syncthreads();  // phase p+1 (staged after the first barrier) landed
+        if (p + 1 < PH && p >= 1) dma_publish_barrier();  // phase p+1 (staged after the first barrier) landed
     }
     __syncthreads();  // every wave is done reading the x image: it becomes the reduction buffer
 #pragma unroll
@@ -1750,21 +1761,23 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
     const int* bt = a.block_tables + (size_t)slot * a.max_blocks;
     const _Float16* kbase = reinterpret_cast<const _Float16*>(a.kv.k);
     const _Float16* vbase = reinterpret_cast<const _Float16*>(a.kv.v);
-    // one 32-token KV tile: 2*DC K fragments (16 rows x 64 B per wave-load) + DT V fragments (1 KiB each)
-    auto load_tile = [&](int kt, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT]) {  // 16 KiB, all 1 KiB wave-loads
-        const int T0 = kt << 5;
-        const int blk = bt[T0 >> 8];
-        const int tb = T0 & 255;
+    // one 32-token KV tile (tokens tb..tb+31 of block blk): 2*DC K fragments + DT V fragments, 16 KiB in 1 KiB wave-loads
+    auto load_tile_at = [&](int blk, int tb, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT]) {
+        auto ld = [&](const _Float16* p) -> uint4 { return *reinterpret_cast<const uint4*>(p); };
         // packed K: the two 16-token tiles of this 32-token step are 2*DC contiguous 1 KiB fragments
         const _Float16* kb = kbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 4) * (DC * 512) + lane * 8;
 #pragma unroll
         for (int c = 0; c < DC; ++c) {
-            ka[c] = *reinterpret_cast<const uint4*>(kb + c * 512);
-            kb2[c] = *reinterpret_cast<const uint4*>(kb + (DC + c) * 512);
+            ka[c] = ld(kb + c * 512);
+            kb2[c] = ld(kb + (DC + c) * 512);
         }
         const _Float16* vb = vbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 5) * (DT * 512);
 #pragma unroll
-        for (int d = 0; d < DT; ++d) vf[d] = *reinterpret_cast<const uint4*>(vb + d * 512 + lane * 8);
+        for (int d = 0; d < DT; ++d) vf[d] = ld(vb + d * 512 + lane * 8);
+    };
+    auto load_tile = [&](int kt, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT]) {
+        const int T0 = kt << 5;
+        load_tile_at(bt[T0 >> 8], T0 & 255, ka, kb2, vf);
     };
     // decode register sets (QT == 1): two 32-token tiles (32 KiB) of this wave are in flight at any time
     uint4 kaA[DC], kbA[DC], vfA[DT], kaB[DC], kbB[DC], vfB[DT];
@@ -1813,9 +1826,16 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
         const float ssq_g = (a.rn.ssq && lane < a.rn.groups) ? a.rn.ssq[(size_t)lane * a.rn.stride + row] : 0.f;
         // This wave's first KV tile goes in flight BEHIND the prologue's own loads (vmcnt retires in order, so the
         // prologue never waits for it) and lands while it computes; a second set would push the kernel to one wave
-        // per SIMD.  A first tile that holds the new token's slot is read again after the barrier below
-        // (contexts of <= 4 tiles only).
-        load_tile(min(t_begin + wave, t_end - 1), kaA, kbA, vfA);
+        // per SIMD.  The tile that holds the new token's slot must NOT be touched before wave 0 has written it: a fill
+        // of those lines still in flight when the stores pass would leave this CU's L1 with the old bytes, and the
+        // re-read after the barrier would hit them (seen as rare wrong K/V under memory load: several contexts decoding
+        // on one GPU).  Such a wave (contexts of <= 4 tiles only) prefetches the neighbouring 32-token tile of the same
+        // block instead -- valid memory, never used -- and reads its real tile after the barrier.
+        {
+            const int e = min(t_begin + wave, t_end - 1), eT0 = e << 5;
+            const int etb = (eT0 & 255) ^ (e == (pos >> 5) ? 32 : 0);
+            load_tile_at(bt[eT0 >> 8], etb, kaA, kbA, vfA);
+        }
         const float ri = a.rn.ssq ? 1.0f / sqrtf(wave_sum(ssq_g) * a.rn.inv_h + a.rn.eps) : 1.0f;
         for (int sl0 = 1; sl0 < a.n_slabs; sl0 += 2) {  // split-K slabs of the generic path's QKV GEMM, two per trip
             const size_t so0 = (size_t)sl0 * a.slab_stride, so1 = (size_t)min(sl0 + 1, a.n_slabs - 1) * a.slab_stride;
@@ -1972,7 +1992,12 @@ __global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
             int kt = t_begin + wave;
             if constexpr (FUSED) {
                 const int last = pmax >> 5;  // the tile wave 0 has just written the new token into
-                if (kt < t_end && kt == last) load_tile(kt, kaA, kbA, vfA);
+                if (kt < t_end && kt == last) {
+                    // no line of this tile can be in this CU's L1 (nobody touched it before the barrier); the agent-scope
+                    // acquire (buffer_inv sc1) makes that independent of who else shares the CU.  Rare path: short contexts.
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    load_tile(kt, kaA, kbA, vfA);
+                }
                 load_tile(min(kt + NWV, t_end - 1), kaB, kbB, vfB);
             } else {
                 load_tile(min(kt, t_end - 1), kaA, kbA, vfA);

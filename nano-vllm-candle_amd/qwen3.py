@@ -265,10 +265,6 @@ class Qwen3ForCausalLM:
         _lib.check(_lib.lib().nvllm_profile_read(self.h, C.byref(ms), C.byref(n)), self.ctx.h)
         return ms.value, n.value
 
-    def set_decode_mode(self, micro_groups=-1, use_graph=-1):
-        """A/B switch of the decode step's execution form (row-group streams, hipGraph replay); -1 = default"""
-        _lib.check(_lib.lib().nvllm_debug_set_decode_mode(self.h, int(micro_groups), int(use_graph)), self.ctx.h)
-
     def enable_taps(self, on=True):
         _lib.check(_lib.lib().nvllm_debug_enable_taps(self.h, int(on)), self.ctx.h)
 
