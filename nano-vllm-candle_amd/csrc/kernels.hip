@@ -1718,8 +1718,10 @@ hipError_t launch_kv_write_plain(const float* k, const float* v, int rows, const
 //                                                          from the S accumulators (no lane movement)
 // Both products keep the q row on lane&15, so the online-softmax state (m, l) is per-lane.
 // ---------------------------------------------------------------------------------------------------
+// Decode (QT == 1) must keep two waves per SIMD (<= 256 registers): at 229 + 40 the compiler once dropped it to one
+// wave per SIMD on its own and the whole decode step lost 12 %
 template <int HD, int QT, int NWV, bool FUSED>
-__global__ void __launch_bounds__(NWV * 64) attn_paged_kernel(AttnArgs a) {
+__global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(AttnArgs a) {
     constexpr int DC = HD / 32, DT = HD / 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* ml = reinterpret_cast<float*>(smem_raw);                          // [NWV][QT][2][16]

@@ -68,3 +68,37 @@ def test_missing_library_raises(monkeypatch, tmp_path):
     monkeypatch.setattr(pkg._lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(pkg._lib.NvllmLibraryMissing):
         pkg._lib.lib()
+
+
+def _kernel_resources():
+    path = os.path.join(ROOT, "nano-vllm-candle_amd", "kernel_resources.txt")
+    if not os.path.exists(path):
+        pytest.skip("kernel_resources.txt missing: rebuild kernels.o (make -C nano-vllm-candle_amd/csrc)")
+    out = {}
+    for blk in open(path).read().split("Function Name: ")[1:]:
+        lines = blk.strip().splitlines()
+        out[lines[0].strip()] = {k.strip(): int(v) for k, v in (l.split(":", 1) for l in lines[1:])}
+    return out
+
+
+def test_hot_kernels_keep_their_register_budget():
+    # hipcc's own per-kernel report, written beside the library by the build.  The decode path is tuned to exact wave
+    # counts per SIMD: the decode attention kernel at 2 waves (<= 256 registers; at 269 it silently ran at 1 wave per
+    # SIMD and the whole step lost 12 %), the register-direct GEMMs of the 0.6B layer at >= 4 (16-wave workgroups),
+    # none of them with scratch (spills in the inner loop).
+    res = _kernel_resources()
+    want = {  # mangled-name prefix -> minimum waves per SIMD
+        "_ZN5nvllm17attn_paged_kernelILi128ELi1ELi4ELb1EEE": 2,   # fused decode attention, head_dim 128
+        "_ZN5nvllm17attn_paged_kernelILi128ELi1ELi4ELb0EEE": 2,
+        "_ZN5nvllm18gemm_rowdir_kernelILi4ELi16ELi2ELi2EEE": 4,   # QKV        (0.6B: N 4096, K 1024)
+        "_ZN5nvllm18gemm_rowdir_kernelILi1ELi16ELi4ELi0EEE": 4,   # o_proj     (N 1024, K 2048)
+        "_ZN5nvllm18gemm_rowdir_kernelILi6ELi16ELi2ELi1EEE": 4,   # gate/up    (N 6144, K 1024)
+        "_ZN5nvllm18gemm_rowdir_kernelILi1ELi16ELi6ELi0EEE": 4,   # down_proj  (N 1024, K 3072)
+        "_ZN5nvllm13lmhead_kernelILi4ELi5ELi4EEE": 2,             # LM head, 64 rows, vocabulary 151936, K 1024
+    }
+    for prefix, min_waves in want.items():
+        hits = [(n, r) for n, r in res.items() if n.startswith(prefix)]
+        assert len(hits) == 1, (prefix, [n for n, _ in hits])
+        r = hits[0][1]
+        assert r["Occupancy [waves/SIMD]"] >= min_waves, (prefix, r)
+        assert r["ScratchSize [bytes/lane]"] == 0, (prefix, r)
