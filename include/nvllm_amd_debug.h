@@ -23,6 +23,12 @@ extern "C" {
  * elapsed ms and the number of launches since the last read. */
 int nvllm_profile_kernel(nvllm_model* m, int kind);
 int nvllm_profile_read(nvllm_model* m, double* total_ms, int64_t* launches);
+/* Diagnostic build only (make -C nano-vllm-candle_amd/csrc stamps -> libnvllm_amd_stamps.so, select it with NVLLM_LIB):
+ * in-kernel time stamps (100 MHz constant clock) of every launch of the fused decode path.  nvllm_debug_stamps arms /
+ * disarms the recording; nvllm_debug_stamps_read copies launch `launch` of the last step, [1024 workgroups][16 waves][8
+ * points] u64, 0 = not written (131072 u64).  The product library returns NVLLM_ESTATE: no stamp code is compiled in. */
+int nvllm_debug_stamps(nvllm_model* m, int enable);
+int nvllm_debug_stamps_read(nvllm_model* m, int launch, uint64_t* out, int64_t capacity_u64);
 /* copy per-layer taps of the last step to the host (debug/parity): what = 0 layer output h,
  * 1 residual; [rows, hidden] f32 of layer `layer`; rows = rows of the last step's last chunk */
 int nvllm_debug_layer_tap(nvllm_model* m, int layer, int what, float* out, int64_t capacity_floats);

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnvllm_amd.so")
+# NVLLM_LIB selects another build of the same library in this directory (the stamped diagnostic build)
+LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ.get("NVLLM_LIB", "libnvllm_amd.so")))
 
 OK, EINVAL, EHIP, ENOMEM, ESTATE, ERCCL = 0, -1, -2, -3, -4, -5
 DTYPE_F32, DTYPE_BF16 = 0, 1
@@ -66,6 +67,8 @@ _SIGS = {
     "nvllm_decode_enqueue": (C.c_int, [_vp]),
     "nvllm_decode_collect": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "nvllm_last_step_bytes": (C.c_int64, [_vp]),
+    "nvllm_debug_stamps": (C.c_int, [_vp, C.c_int]),
+    "nvllm_debug_stamps_read": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64), C.c_int64]),
     "nvllm_profile_kernel": (C.c_int, [_vp, C.c_int]),
     "nvllm_profile_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "nvllm_debug_layer_tap": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int64]),
@@ -105,6 +108,8 @@ def lib():
                 "(make -C nano-vllm-candle_amd/csrc).  There is no CPU fallback.")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
+            if name.startswith("nvllm_debug_") and not hasattr(L, name):
+                continue  # an older build selected with NVLLM_LIB / tools/ab_bench.sh may lack a debug export
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
         _lib = L

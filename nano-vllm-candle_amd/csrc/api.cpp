@@ -342,11 +342,27 @@ struct nvllm_model {
     std::vector<int> pending;
     int pend_next = 0;
 
+    // diagnostic build (-DNVLLM_STAMPS): in-kernel time stamps of every launch of the fused decode path
+    unsigned long long* stamps = nullptr;
+    bool stamps_on = false;
+    int stamp_launch = 0;
+
     // per-kernel-class HIP-event timing (bench roofline leg); 0 = off
     int prof_kind = 0;
     std::vector<hipEvent_t> prof_ev;
     size_t prof_used = 0;
 };
+
+#ifdef NVLLM_STAMPS
+constexpr int kStampLaunches = 160;               // launches recorded per step (fused decode path: 5 per layer)
+constexpr size_t kStampStride = (size_t)1024 * 16 * 8;  // u64 per launch: [<= 1024 workgroups][16 waves][8 points]
+#define STAMPS(args_, m_)                                                                                        \
+    do {                                                                                                         \
+        if ((m_)->stamps_on && (m_)->stamp_launch < kStampLaunches) (args_).stamps = (m_)->stamps + (size_t)((m_)->stamp_launch++) * kStampStride; \
+    } while (0)
+#else
+#define STAMPS(args_, m_) do { } while (0)
+#endif
 
 enum { PROF_ATTN = 1, PROF_GEMM = 2, PROF_NORM = 3, PROF_QK = 4, PROF_SILU = 5, PROF_LMHEAD = 6, PROF_EMPTY = 7 };
 
@@ -840,6 +856,7 @@ static int tp_reduce(nvllm_model* m, int rows, int ns, const float** in, int* n_
 // ---------------------------------------------------------------------------------------------------
 static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n_last, int logits_row0) {
     nvllm_ctx* ctx = m->ctx;
+    m->stamp_launch = 0;
     hipStream_t s = ctx->stream;
     const int H = m->H, hd = m->hd;
     const float eps = (float)m->cfg.rms_norm_eps;
@@ -866,6 +883,7 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
             RowParArgs rq;
             rq.xh = m->xh; rq.xl = m->xl; rq.ldx = H; rq.out = m->slabs; rq.M = R; rq.x_packed = packed;
             if (gemm_rowpar_ok(NQ, H, 2, R)) {
+                STAMPS(rq, m);
                 PROF(m, PROF_GEMM, launch_gemm_rowpar(rq, w.qkv, 2, s));
                 qa.n_slabs = 1;
             } else {
@@ -897,12 +915,14 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
             parts_max = m->attn_parts_max;
         }
         PROF(m, PROF_EMPTY, hipSuccess);  // calibration: an event pair around nothing, at the attention launch's place
+        STAMPS(aa, m);
         PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
         // o_proj + residual + post-attention norm prep (qwen3.rs:278, :393)
         RowParArgs ra;
         ra.xh = m->ctxh; ra.xl = m->ctxl; ra.ldx = KO; ra.resid_in = m->resid; ra.resid_out = m->resid; ra.next_w = w.ln2;
         ra.oh = m->xh; ra.ol = m->xl; ra.ssq = m->ssqA; ra.ssq_stride = kFusedMaxRows; ra.M = R;
         ra.x_packed = packed; ra.o_packed = packed;
+        STAMPS(ra, m);
         PROF(m, PROF_GEMM, launch_gemm_rowpar(ra, w.o, 0, s));
         rn.ssq = m->ssqA; rn.groups = gemm_rowpar_groups(H, KO);
         // gate/up + SiLU*mul (qwen3.rs:324-325), scaled by the pending norm's rinv
@@ -911,6 +931,7 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
             rg.xh = m->xh; rg.xl = m->xl; rg.ldx = H; rg.oh = m->xh2; rg.ol = m->xl2; rg.M = R; rg.rn = rn;
             rg.x_packed = packed; rg.o_packed = packed;
             if (gemm_rowpar_ok(2 * m->I_l, H, 1, R)) {
+                STAMPS(rg, m);
                 PROF(m, PROF_GEMM, launch_gemm_rowpar(rg, w.gu, 1, s));
             } else {
                 GemmPlan pg = plan_gemm_swiglu(R, 2 * m->I_l, H);
@@ -923,6 +944,7 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
         rd.next_w = l + 1 < m->L ? m->layers[l + 1].ln1 : m->norm;
         rd.oh = m->xh; rd.ol = m->xl; rd.ssq = m->ssqB; rd.ssq_stride = kFusedMaxRows; rd.M = R;
         rd.x_packed = packed; rd.o_packed = packed && l + 1 < m->L;  // the LM head (chunked kernel) reads row-major planes
+        STAMPS(rd, m);
         PROF(m, PROF_GEMM, launch_gemm_rowpar(rd, w.down, 0, s));
         rn.ssq = m->ssqB; rn.groups = gemm_rowpar_groups(H, m->I_l);
     }
@@ -1410,6 +1432,34 @@ extern "C" int nvllm_decode_collect(nvllm_model* m, uint32_t* next_ids) {
 }
 
 extern "C" int64_t nvllm_last_step_bytes(const nvllm_model* m) { return m ? m->last_bytes : 0; }
+
+// Diagnostic build only (make -C csrc stamps): record s_memrealtime stamps inside every kernel of the fused decode path.
+// enable != 0 arms the recording for the following steps; read copies launch `launch` of the LAST step:
+// [1024 workgroups][16 waves][8 points] u64 (zero = not written), launches in issue order (QKV, attention, o_proj,
+// gate/up, down per layer).  The product library returns NVLLM_ESTATE.
+extern "C" int nvllm_debug_stamps(nvllm_model* m, int enable) {
+    if (!m) return NVLLM_EINVAL;
+#ifdef NVLLM_STAMPS
+    HIPCHK(m->ctx, hipStreamSynchronize(m->ctx->stream));
+    if (enable && !m->stamps) HIPCHK(m->ctx, hipMalloc((void**)&m->stamps, kStampLaunches * kStampStride * 8));
+    if (enable) HIPCHK(m->ctx, hipMemset(m->stamps, 0, kStampLaunches * kStampStride * 8));
+    m->stamps_on = enable != 0;
+    return NVLLM_OK;
+#else
+    return fail(m->ctx, NVLLM_ESTATE, "library built without NVLLM_STAMPS (make -C nano-vllm-candle_amd/csrc stamps)");
+#endif
+}
+extern "C" int nvllm_debug_stamps_read(nvllm_model* m, int launch, uint64_t* out, int64_t capacity_u64) {
+    if (!m || !out) return NVLLM_EINVAL;
+#ifdef NVLLM_STAMPS
+    if (!m->stamps || launch < 0 || launch >= kStampLaunches || capacity_u64 < (int64_t)kStampStride) return fail(m->ctx, NVLLM_EINVAL, "bad stamps_read arguments");
+    HIPCHK(m->ctx, hipStreamSynchronize(m->ctx->stream));
+    HIPCHK(m->ctx, hipMemcpy(out, m->stamps + (size_t)launch * kStampStride, kStampStride * 8, hipMemcpyDeviceToHost));
+    return NVLLM_OK;
+#else
+    return fail(m->ctx, NVLLM_ESTATE, "library built without NVLLM_STAMPS");
+#endif
+}
 
 extern "C" int nvllm_profile_kernel(nvllm_model* m, int kind) {
     if (!m || kind < 0 || kind > PROF_EMPTY) return NVLLM_EINVAL;

@@ -180,6 +180,9 @@ struct AttnArgs {
     int part_tiles = 0, max_parts = 0;
     float* part_o = nullptr;           // [rows][nh_l][max_parts][hd]
     float* part_ml = nullptr;          // [rows][nh_l][max_parts][2]
+#ifdef NVLLM_STAMPS
+    unsigned long long* stamps = nullptr;  // diagnostic build only: [workgroup][16 waves][8] s_memrealtime stamps
+#endif
 };
 // qt = q sub-tiles (of 16 MFMA rows) per workgroup: 1 (decode) or 2 (prefill)
 hipError_t launch_attn_paged(const AttnArgs& a, int n_tiles, int qt, int rows, int n_parts_max, hipStream_t s);
@@ -206,6 +209,9 @@ struct RowParArgs {
     float* out = nullptr;
     RowNorm rn;
     int x_packed = 0, o_packed = 0;  // xh/xl resp. oh/ol in xpack_off order (register-direct kernel only)
+#ifdef NVLLM_STAMPS
+    unsigned long long* stamps = nullptr;  // diagnostic build only: [workgroup][16 waves][8] s_memrealtime stamps
+#endif
 };
 bool gemm_rowpar_supported(int N, int K);
 // true when launch_gemm_rowpar would run the register-direct kernel (the one that accepts packed planes)

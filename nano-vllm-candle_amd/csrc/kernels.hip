@@ -230,6 +230,19 @@ hipError_t launch_split_hilo(const float* x, bf16_bits* hi, bf16_bits* lo, int64
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Diagnostic build (make stamps, -DNVLLM_STAMPS): in-kernel time stamps of the 100 MHz constant clock, one slot per
+// (workgroup, wave, point); tools/stamp_timeline.py reads them.  Compiled out of the product library.
+#ifdef NVLLM_STAMPS
+#define NVLLM_STAMP(args_, idx_)                                                                                          \
+    do {                                                                                                                  \
+        if ((args_).stamps && (threadIdx.x & 63) == 0)                                                                    \
+            (args_).stamps[(((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * 16 + (threadIdx.x >> 6)) * 8 + (idx_)] = \
+                __builtin_amdgcn_s_memrealtime();                                                                         \
+    } while (0)
+#else
+#define NVLLM_STAMP(args_, idx_) do { } while (0)
+#endif
+
 // Barrier that PUBLISHES LDS-DMA data (global_load_lds): every wave first waits for its own DMA to land, then joins the
 // barrier; only then may any wave ds_read fragments another wave staged.  __syncthreads() alone is not enough: hipcc
 // (ROCm 7.2) emitted the loop-header barrier of gemm_kernel's chunk loop as `s_waitcnt lgkmcnt(0); s_barrier` with
@@ -1233,6 +1246,7 @@ __global__ void __launch_bounds__(NWK * 64) gemm_rowdir_kernel(RowParArgs a, con
     const int m0 = blockIdx.z * NR;
     const int M = a.M;
     const int k0 = wave * TK;
+    NVLLM_STAMP(a, 0);
 
     uint4 w[NT][TK];
 #pragma unroll
@@ -1268,6 +1282,7 @@ __global__ void __launch_bounds__(NWK * 64) gemm_rowdir_kernel(RowParArgs a, con
     }
     if constexpr (EPI == 1) rownorm_partials<NR>(a.rn, m0, M, sred);
     __builtin_amdgcn_sched_barrier(0);  // every load above is issued before the first use below (one round trip)
+    NVLLM_STAMP(a, 1);
 
     f32x4 acc[NT];
 #pragma unroll
@@ -1283,9 +1298,14 @@ __global__ void __launch_bounds__(NWK * 64) gemm_rowdir_kernel(RowParArgs a, con
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, bl, acc[t], 0, 0, 0);
         }
     }
+#ifdef NVLLM_STAMPS
+    asm volatile("" ::"v"(acc[0][0]));  // the stamp below is taken after the last MFMA's result exists
+#endif
+    NVLLM_STAMP(a, 2);
 #pragma unroll
     for (int t = 0; t < NT; ++t) red[(size_t)(wave * NT + t) * 64 + lane] = acc[t];
     __syncthreads();
+    NVLLM_STAMP(a, 3);
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     if (wave < NT) {
 #pragma unroll
@@ -1350,6 +1370,7 @@ __global__ void __launch_bounds__(NWK * 64) gemm_rowdir_kernel(RowParArgs a, con
         if (fin && row < M)
             *reinterpret_cast<float4*>(a.out + (size_t)row * N + (size_t)ntile * 16 + grp * 4) = make_float4(sum[0], sum[1], sum[2], sum[3]);
     }
+    NVLLM_STAMP(a, 4);
 }
 
 // shape of the register-direct kernel for (N, K, epi, M): nt == 0 -> not applicable
@@ -1720,6 +1741,12 @@ hipError_t launch_kv_write_plain(const float* k, const float* v, int rows, const
 // ---------------------------------------------------------------------------------------------------
 // Decode (QT == 1) must keep two waves per SIMD (<= 256 registers): at 229 + 40 the compiler once dropped it to one
 // wave per SIMD on its own and the whole decode step lost 12 %
+// Where the prefetch of a tile PAST the end of a context goes: 16 KiB every workgroup shares (L1/L2-resident).  The decode
+// loop keeps its loads unconditional (a branch around them makes hipcc wait vmcnt(0) per load), and a wave leaves the
+// loop with two such prefetches in flight; pointed at the context's last tile they were 32 KiB of real L2 traffic per
+// wave (64 MB per launch at batch 64 beside 87 MB of K/V) that every wave then waited for at the combine barrier.
+__device__ uint4 g_attn_dummy_tile[1024];
+
 template <int HD, int QT, int NWV, bool FUSED>
 __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(AttnArgs a) {
     constexpr int DC = HD / 32, DT = HD / 16;
@@ -1731,6 +1758,7 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
     const int l15 = lane & 15, grp = lane >> 4;
     int tile = blockIdx.x;
     const int kh = blockIdx.y;
+    NVLLM_STAMP(a, 0);
     if (a.tile_order) {
         const int lin = blockIdx.y * gridDim.x + blockIdx.x;
         const int rank = ((lin >> 8) & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
@@ -1780,6 +1808,23 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
     auto load_tile = [&](int kt, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT]) {
         const int T0 = kt << 5;
         load_tile_at(bt[T0 >> 8], T0 & 255, ka, kb2, vf);
+    };
+    // tile kt if it exists (kt < t_end), else the shared dummy tile (same instruction stream, no K/V traffic)
+    // avoid: a tile that must not be touched yet (see the fused prologue): its 32-token neighbour in the block is read instead
+    auto load_tile_or_dummy = [&](int kt, int t_end_, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], int avoid = -1) {
+        const bool real = kt < t_end_;
+        const int T0 = min(kt, t_end_ - 1) << 5;
+        const int blk = bt[T0 >> 8], tb = (T0 & 255) ^ (kt == avoid ? 32 : 0);
+        const _Float16* dummy = reinterpret_cast<const _Float16*>(g_attn_dummy_tile) + lane * 8;
+        const _Float16* kb = real ? kbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 4) * (DC * 512) + lane * 8 : dummy;
+        const _Float16* vb = real ? vbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 5) * (DT * 512) + lane * 8 : dummy;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            ka[c] = *reinterpret_cast<const uint4*>(kb + c * 512);
+            kb2[c] = *reinterpret_cast<const uint4*>(kb + (DC + c) * 512);
+        }
+#pragma unroll
+        for (int d = 0; d < DT; ++d) vf[d] = *reinterpret_cast<const uint4*>(vb + d * 512);
     };
     // decode register sets (QT == 1): two 32-token tiles (32 KiB) of this wave are in flight at any time
     uint4 kaA[DC], kbA[DC], vfA[DT], kaB[DC], kbB[DC], vfB[DT];
@@ -1833,11 +1878,11 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
         // re-read after the barrier would hit them (seen as rare wrong K/V under memory load: several contexts decoding
         // on one GPU).  Such a wave (contexts of <= 4 tiles only) prefetches the neighbouring 32-token tile of the same
         // block instead -- valid memory, never used -- and reads its real tile after the barrier.
-        {
-            const int e = min(t_begin + wave, t_end - 1), eT0 = e << 5;
-            const int etb = (eT0 & 255) ^ (e == (pos >> 5) ? 32 : 0);
-            load_tile_at(bt[eT0 >> 8], etb, kaA, kbA, vfA);
-        }
+        // Wave 0 (the K/V producer) prefetches nothing here: its vmcnt(0) behind the K/V stores would also wait for the
+        // tile (vmcnt retires in order) -- 16 KiB queued behind every other wave's first tile -- and the whole workgroup
+        // waits for wave 0 at the barrier (in-kernel stamps: 7 us to the barrier, 3 us in it).  It loads its first tile
+        // after the barrier instead.
+        if (wave != 0) load_tile_or_dummy(t_begin + wave, t_end, kaA, kbA, vfA, pos >> 5);
         const float ri = a.rn.ssq ? 1.0f / sqrtf(wave_sum(ssq_g) * a.rn.inv_h + a.rn.eps) : 1.0f;
         for (int sl0 = 1; sl0 < a.n_slabs; sl0 += 2) {  // split-K slabs of the generic path's QKV GEMM, two per trip
             const size_t so0 = (size_t)sl0 * a.slab_stride, so1 = (size_t)min(sl0 + 1, a.n_slabs - 1) * a.slab_stride;
@@ -1908,7 +1953,9 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
                 ql[0][c + DC / 2][j] = (_Float16)(y2 - (float)h2);
             }
         }
+        NVLLM_STAMP(a, 1);
         __syncthreads();  // the new token's K/V (written by wave 0 above) is visible from here on
+        NVLLM_STAMP(a, 2);
     } else {
 #pragma unroll
         for (int t = 0; t < QT; ++t)
@@ -1999,19 +2046,27 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
                     // acquire (buffer_inv sc1) makes that independent of who else shares the CU.  Rare path: short contexts.
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     load_tile(kt, kaA, kbA, vfA);
+                } else if (wave == 0) {
+                    load_tile_or_dummy(kt, t_end, kaA, kbA, vfA);  // wave 0 skipped the early prefetch
                 }
-                load_tile(min(kt + NWV, t_end - 1), kaB, kbB, vfB);
+                load_tile_or_dummy(kt + NWV, t_end, kaB, kbB, vfB);
             } else {
                 load_tile(min(kt, t_end - 1), kaA, kbA, vfA);
                 load_tile(min(kt + NWV, t_end - 1), kaB, kbB, vfB);
             }
+            // refills past the end: the shared dummy tile (fused kernel: the one the model runs); the plain-q variant
+            // (fine-seam op, tuning bench) keeps the clamped re-read -- the extra address selects would spill it
+            auto refill = [&](int kt_next, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT]) {
+                if constexpr (FUSED) load_tile_or_dummy(kt_next, t_end, ka, kb2, vf);
+                else load_tile(min(kt_next, t_end - 1), ka, kb2, vf);
+            };
             while (kt < t_end) {
                 compute_tile(kt, kaA, kbA, vfA);
-                load_tile(min(kt + 2 * NWV, t_end - 1), kaA, kbA, vfA);
+                refill(kt + 2 * NWV, kaA, kbA, vfA);
                 kt += NWV;
                 if (kt >= t_end) break;
                 compute_tile(kt, kaB, kbB, vfB);
-                load_tile(min(kt + 2 * NWV, t_end - 1), kaB, kbB, vfB);
+                refill(kt + 2 * NWV, kaB, kbB, vfB);
                 kt += NWV;
             }
         } else {
@@ -2024,6 +2079,7 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
     }
 
     // combine the NWV waves' partial (m, l, O)
+    NVLLM_STAMP(a, 3);
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         float l = lsum[t];
@@ -2097,6 +2153,7 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
             pm[1] = ltot[t];
         }
     }
+    NVLLM_STAMP(a, 4);
 }
 
 // merge the split-KV partials of one (row, q head): one wave each, lane = 2 (HD 128) or 1 (HD 64) dims
