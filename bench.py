@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--tp-timeout", type=float, default=300.0)
     ap.add_argument("--force-device", type=int, default=-1, help="testing aid: every rank uses this GPU ordinal")
     ap.add_argument("--tp-leg-child", action="store_true", help=argparse.SUPPRESS)  # internal: run only the TP leg
+    ap.add_argument("--tp-proj-child", type=int, default=0, help=argparse.SUPPRESS)  # internal: one projection point (TP degree)
+    ap.add_argument("--skip-tp-projection", action="store_true",
+                    help="do not run the per-rank projection of the TP leg at TP = 2/4/8 (null communicator, one GPU)")
     ap.add_argument("--prefill-only", action="store_true",
                     help="time the prefill of the batch (cold call + warmed repeats) and stop: the MFMA-side profile run")
     ap.add_argument("--prefill-reps", type=int, default=3)
@@ -170,6 +173,36 @@ def spawn_ranks(n):
     return 0
 
 
+def run_tp_projection_point(pkg, a, tp):
+    """Per-rank compute time of one TP decode step WITHOUT a multi-GPU node: rank 0 of a tp-way group on a null
+    communicator (the rank's shard shapes and kernels, every collective skipped).  Results of such a step are
+    meaningless; its duration bounds what TP = tp can reach: step(tp) >= this + 2 * layers all-reduces."""
+    import numpy as np
+
+    ctx = pkg.Context(0, tp_rank=0, tp_size=tp, null_comm=True)
+    cfg = model_config(pkg, a.tp_model)
+    model = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=a.seed, ctx=ctx)
+    B, P, steps, warm = a.tp_batch, a.tp_prompt, min(a.tp_steps, 16), 4
+    rng = np.random.default_rng(a.seed + 1)
+    prompts = [rng.integers(0, cfg.vocab_size, size=P, dtype=np.uint32).tolist() for _ in range(B)]
+    model.kv_alloc(num_blocks=B * (-(-(P + steps + warm + 4) // 256)) + 2, max_seqs=B, max_batched_tokens=4096)
+    model.step(list(range(B)), prompts, is_prefill=True)
+    for _ in range(warm):
+        model.decode_next()
+    ctx.synchronize()
+    ctx.timer_start()
+    byts = 0
+    for _ in range(steps):
+        model.decode_next()
+        byts += model.last_step_bytes
+    ms = ctx.timer_stop() / steps
+    res = {"tp": tp, "per_rank_ms_per_step": ms, "per_rank_bytes_per_step": byts / steps,
+           "per_rank_hbm_frac": (byts / steps) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    model.close()
+    ctx.close()
+    return res
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -206,6 +239,9 @@ def main():
             dist.destroy_process_group()
         return
     torch.cuda.set_device(local_rank)
+    if a.tp_proj_child:
+        print("TP_PROJ_RESULT " + json.dumps(run_tp_projection_point(pkg, a, a.tp_proj_child)), flush=True)
+        return
     if a.tp_leg_child:
         # child process of a bench rank: only the tensor-parallel leg, result as one JSON line on stdout (rank 0)
         res = run_tp_extra(pkg, torch, dist, a, rank, world, local_rank)
@@ -415,6 +451,28 @@ def main():
         except Exception as e:  # noqa: BLE001
             tp_res = {"model": a.tp_model, "tp": world, "error": repr(e)[:300]}
         out["tp_scaling"] = tp_res
+        # projection of the same leg at TP = 2/4/8 on THIS GPU (rank 0's shard, null communicator): N = 1 only
+        if world == 1 and not a.skip_tp_projection and "ms_per_step" in tp_res:
+            proj = {"label": "projected_not_measured: rank 0's shard shapes and kernels on one GPU, every collective skipped; "
+                             "a real TP step adds 2 all-reduces of [batch, hidden] f32 per layer + the (max, index) gather",
+                    "model": a.tp_model, "batch": a.tp_batch, "prompt": a.tp_prompt, "tp1_ms_per_step": tp_res["ms_per_step"], "points": []}
+            for tpd in (2, 4, 8):
+                cmdp = [sys.executable, os.path.abspath(__file__), "--tp-proj-child", str(tpd), "--tp-model", a.tp_model,
+                        "--tp-batch", str(a.tp_batch), "--tp-prompt", str(a.tp_prompt), "--tp-steps", str(a.tp_steps), "--seed", str(a.seed)]
+                pt = {"tp": tpd, "error": "no result"}
+                try:
+                    cpp = subprocess.run(cmdp, env=dict(os.environ), capture_output=True, text=True, timeout=a.tp_timeout)
+                    for line in cpp.stdout.splitlines():
+                        if line.startswith("TP_PROJ_RESULT "):
+                            pt = json.loads(line[len("TP_PROJ_RESULT "):])
+                    if "error" in pt:
+                        pt["error"] = f"child exit {cpp.returncode}: " + (cpp.stderr.strip().splitlines() or ["?"])[-1][:200]
+                except Exception as e:  # noqa: BLE001
+                    pt = {"tp": tpd, "error": repr(e)[:200]}
+                if "per_rank_ms_per_step" in pt:
+                    pt["compute_only_speedup_vs_tp1"] = tp_res["ms_per_step"] / pt["per_rank_ms_per_step"]
+                proj["points"].append(pt)
+            out["tp_projection"] = proj
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -127,6 +127,15 @@ int nvllm_seq_free(nvllm_model* m, int64_t seq_id);
 int nvllm_step(nvllm_model* m, int n_seqs, const int64_t* seq_ids, const uint32_t* const* tokens,
                const int32_t* lens, int is_prefill, uint32_t* next_ids, float* last_logits);
 
+/* The same step with the reference's sample_token on the device (src/engine/llm_engine.rs:97-133) instead of the greedy
+ * arg-max: next_ids[i] is drawn from softmax(logits_i / max(temperatures[i], 1e-6)); a row whose weights do not form a
+ * distribution falls back to the arg-max (last max), as the reference does.  The draw is the Gumbel-max form over a
+ * counter RNG keyed by (seed, seq_id, position): reproducible for a given seed and independent of batch composition
+ * (the reference uses an unseeded thread RNG, so only the distribution can be compared with it).  last_logits as above. */
+int nvllm_step_sample(nvllm_model* m, int n_seqs, const int64_t* seq_ids, const uint32_t* const* tokens,
+                      const int32_t* lens, int is_prefill, const float* temperatures, uint64_t seed,
+                      uint32_t* next_ids, float* last_logits);
+
 /* Decode fast path for benchmarks and engines that keep ids on the device: one more decode step for
  * the same batch as the previous nvllm_step / nvllm_decode_next call, feeding each sequence the id
  * produced by that call.  No host<->device traffic besides next_ids (nullable). */

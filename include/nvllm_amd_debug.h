@@ -15,6 +15,11 @@
 extern "C" {
 #endif
 
+/* Projection aid: rank tp_rank of a tp_size group WITHOUT a communicator.  Models created on it take the rank's shard
+ * shapes and run the rank's kernels; every collective is skipped, so a step's results are meaningless and only its
+ * duration (per-rank compute time of a tensor-parallel step) is of use.  bench.py reports it as projected_not_measured. */
+int nvllm_ctx_create_null_comm(int device_ordinal, int tp_rank, int tp_size, nvllm_ctx** out);
+
 /* HIP-event timing of one kernel class on the library stream (bench.py's roofline leg):
  * kind 0 off, 1 paged attention, 2 layer GEMMs, 3 add+RMSNorm, 4 qk-norm/RoPE/KV-write, 5 SwiGLU, 6 LM head,
  * 7 calibration (an event pair around NO launch, recorded where the decode attention launch sits: the elapsed
@@ -23,6 +28,10 @@ extern "C" {
  * elapsed ms and the number of launches since the last read. */
 int nvllm_profile_kernel(nvllm_model* m, int kind);
 int nvllm_profile_read(nvllm_model* m, double* total_ms, int64_t* launches);
+/* tuning switches of a model (A/B runs and tests).  "stream_combine" (default 0): let the fused forward use the streaming
+ * GEMM's in-launch split-K combine epilogues (fewer launches; measured slower on MI355X than slabs + a consumer launch). */
+int nvllm_debug_set_option(nvllm_model* m, const char* name, int value);
+
 /* Diagnostic build only (make -C nano-vllm-candle_amd/csrc stamps -> libnvllm_amd_stamps.so, select it with NVLLM_LIB):
  * in-kernel time stamps (100 MHz constant clock) of every launch of the fused decode path.  nvllm_debug_stamps arms /
  * disarms the recording; nvllm_debug_stamps_read copies launch `launch` of the last step, [1024 workgroups][16 waves][8

@@ -43,6 +43,7 @@ _SIGS = {
     "nvllm_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "nvllm_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(_vp)]),
     "nvllm_ctx_create_loopback": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_char_p, C.POINTER(_vp)]),
+    "nvllm_ctx_create_null_comm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "nvllm_ctx_destroy": (C.c_int, [_vp]),
     "nvllm_ctx_synchronize": (C.c_int, [_vp]),
     "nvllm_ctx_stream": (C.c_void_p, [_vp]),
@@ -63,10 +64,13 @@ _SIGS = {
     "nvllm_seq_free": (C.c_int, [_vp, C.c_int64]),
     "nvllm_step": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_uint32)),
                              C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
+    "nvllm_step_sample": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_int32), C.c_int,
+                                    C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "nvllm_decode_next": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "nvllm_decode_enqueue": (C.c_int, [_vp]),
     "nvllm_decode_collect": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "nvllm_last_step_bytes": (C.c_int64, [_vp]),
+    "nvllm_debug_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "nvllm_debug_stamps": (C.c_int, [_vp, C.c_int]),
     "nvllm_debug_stamps_read": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint64), C.c_int64]),
     "nvllm_profile_kernel": (C.c_int, [_vp, C.c_int]),
@@ -94,6 +98,7 @@ _SIGS = {
     "nvllm_dev_download": (C.c_int, [_vp, C.c_void_p, _vp, C.c_size_t]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
+_DEBUG_EXPORTS_ADDED_LATER = ("nvllm_debug_stamps", "nvllm_debug_stamps_read", "nvllm_ctx_create_null_comm", "nvllm_debug_set_option")
 
 _lib = None
 
@@ -108,8 +113,8 @@ def lib():
                 "(make -C nano-vllm-candle_amd/csrc).  There is no CPU fallback.")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
-            if name.startswith("nvllm_debug_") and not hasattr(L, name):
-                continue  # an older build selected with NVLLM_LIB / tools/ab_bench.sh may lack a debug export
+            if name in _DEBUG_EXPORTS_ADDED_LATER and not hasattr(L, name):
+                continue  # an older build swapped in by tools/ab_bench.sh may lack a newer debug export
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
         _lib = L

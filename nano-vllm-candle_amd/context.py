@@ -9,9 +9,14 @@ from . import _lib
 class Context:
     """nvllm_ctx: one GPU, one stream, optional RCCL communicator (TP group)."""
 
-    def __init__(self, device=0, tp_rank=0, tp_size=1, rccl_id=None, loopback_group=None):
+    def __init__(self, device=0, tp_rank=0, tp_size=1, rccl_id=None, loopback_group=None, null_comm=False):
         L = _lib.lib()
         h = C.c_void_p()
+        if null_comm:  # projection aid: the rank's shard shapes, collectives skipped (results meaningless)
+            _lib.check(L.nvllm_ctx_create_null_comm(device, tp_rank, tp_size, C.byref(h)), None)
+            self.h = h
+            self.device = device
+            return
         if loopback_group is not None:  # test-only in-process communicator (one host thread per rank)
             _lib.check(L.nvllm_ctx_create_loopback(device, tp_rank, tp_size, loopback_group.encode(), C.byref(h)), None)
             self.h = h

@@ -46,6 +46,7 @@ static std::map<std::string, std::shared_ptr<LoopGroup>> g_groups;
 
 struct nvllm_ctx {
     std::shared_ptr<LoopGroup> loop;
+    bool null_comm = false;  // projection mode: tp_size > 1 shard shapes, every collective skipped (results meaningless)
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -79,7 +80,7 @@ static int fail(nvllm_ctx* ctx, int code, const char* fmt, ...) {
 
 // ---- collectives: RCCL on the library stream, or the in-process loopback group ----------------------
 static int comm_allreduce_sum(nvllm_ctx* ctx, float* buf, size_t n) {
-    if (ctx->tp_size == 1) return NVLLM_OK;
+    if (ctx->tp_size == 1 || ctx->null_comm) return NVLLM_OK;
     if (!ctx->loop) {
         NCCLCHK(ctx, ncclAllReduce(buf, buf, n, ncclFloat, ncclSum, ctx->comm, ctx->stream));
         return NVLLM_OK;
@@ -112,6 +113,7 @@ static int comm_allreduce_sum(nvllm_ctx* ctx, float* buf, size_t n) {
 
 // recv[r*bytes .. ) = rank r's send (send may alias recv + rank*bytes)
 static int comm_allgather(nvllm_ctx* ctx, const void* send, void* recv, size_t bytes) {
+    if (ctx->null_comm) return NVLLM_OK;  // the rank's own slot already holds its part
     if (!ctx->loop) {
         NCCLCHK(ctx, ncclAllGather(send, recv, bytes, ncclUint8, ctx->comm, ctx->stream));
         return NVLLM_OK;
@@ -203,6 +205,19 @@ extern "C" int nvllm_ctx_create_loopback(int device_ordinal, int tp_rank, int tp
     if (!g) { g = std::make_shared<LoopGroup>(); g->size = tp_size; }
     if (g->size != tp_size) { nvllm_ctx_destroy(*out); *out = nullptr; return fail(nullptr, NVLLM_EINVAL, "loopback group size mismatch"); }
     (*out)->loop = g;
+    return NVLLM_OK;
+}
+
+// Projection mode (bench.py tp_projection): one rank of a tp_size group with NO communicator.  The model takes the
+// rank's shard shapes and runs the rank's kernels; all-reduce / all-gather are skipped, so the numbers a step produces
+// are meaningless -- only its duration (the per-rank compute time of a TP step) is.
+extern "C" int nvllm_ctx_create_null_comm(int device_ordinal, int tp_rank, int tp_size, nvllm_ctx** out) {
+    if (!out || tp_size < 1 || tp_rank < 0 || tp_rank >= tp_size) return fail(nullptr, NVLLM_EINVAL, "bad null-comm arguments");
+    int rc = nvllm_ctx_create(device_ordinal, 0, 1, nullptr, out);
+    if (rc) return rc;
+    (*out)->tp_rank = tp_rank;
+    (*out)->tp_size = tp_size;
+    (*out)->null_comm = true;
     return NVLLM_OK;
 }
 
@@ -315,7 +330,14 @@ struct nvllm_model {
     float *resid = nullptr, *slabs = nullptr, *qbuf = nullptr, *logits = nullptr, *d_maxval = nullptr, *red = nullptr;
     bf16_bits *xh = nullptr, *xl = nullptr, *xh2 = nullptr, *xl2 = nullptr, *ctxh = nullptr, *ctxl = nullptr;
     float *ssqA = nullptr, *ssqB = nullptr;  // deferred-norm partial sums of squares [groups][kFusedMaxRows]
-    bool fused_ok = false;                   // row-parallel fused decode path available for this model's shapes
+    uint64_t* d_keys = nullptr;              // device sampling: per-row RNG keys and temperatures
+    float* d_temps = nullptr;
+    // The streaming GEMM's in-launch split-K combine (epilogues 1-3) is OFF by default: measured slower than slabs + a
+    // consumer launch on MI355X (Qwen3-8B batch 64: 8.6 vs 6.4 ms/step; 32B TP=8 shard: 8.9 vs 6.5 ms) -- one workgroup
+    // per n-group reads every slab behind an agent-scope release of all the others.  nvllm_debug_set_option turns it on.
+    int opt_stream_combine = 0;
+    unsigned* tickets = nullptr;             // arrival counters of the streaming GEMM's in-launch combine (zero between launches)
+    float* qkv_out = nullptr;                // complete QKV sums of the streaming GEMM (its combine reads the slabs in m->slabs)
     uint32_t* d_next = nullptr;
     float *attn_po = nullptr, *attn_pml = nullptr;  // split-KV partials [max_seqs][nh_l][kAttnMaxParts][hd] / [..][2]
     int attn_part_tiles = 4, attn_parts_max = 1;   // this step's split geometry (decode only)
@@ -457,11 +479,11 @@ static void free_kv(nvllm_model* m) {
     m->kcache.clear(); m->vcache.clear();
     void* ptrs[] = {m->d_block_tables, m->d_ids, m->d_pos, m->d_slot, m->d_tile_row0, m->d_tile_nrows, m->d_tile_slot,
                     m->d_last_rows, m->d_tile_order, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->xh2, m->xl2, m->ctxh, m->ctxl, m->ssqA, m->ssqB, m->d_next,
-                    m->part_val, m->part_idx, m->argmax_scratch, m->attn_po, m->attn_pml, m->tap_h, m->tap_res, m->cosv, m->sinv};
+                    m->part_val, m->part_idx, m->argmax_scratch, m->attn_po, m->attn_pml, m->tap_h, m->tap_res, m->cosv, m->sinv, m->tickets, m->qkv_out, m->d_keys, m->d_temps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     m->d_block_tables = nullptr; m->d_ids = nullptr; m->d_pos = m->d_slot = m->d_tile_row0 = m->d_tile_nrows = m->d_tile_slot = m->d_last_rows = m->d_tile_order = nullptr;
     m->resid = m->slabs = m->qbuf = m->logits = m->d_maxval = m->red = nullptr; m->xh = m->xl = m->xh2 = m->xl2 = m->ctxh = m->ctxl = nullptr; m->ssqA = m->ssqB = nullptr; m->d_next = nullptr; m->part_val = nullptr; m->part_idx = nullptr; m->argmax_scratch = nullptr; m->attn_po = m->attn_pml = nullptr;
-    m->tap_h = m->tap_res = nullptr; m->cosv = m->sinv = nullptr;
+    m->tap_h = m->tap_res = nullptr; m->cosv = m->sinv = nullptr; m->tickets = nullptr; m->qkv_out = nullptr; m->d_keys = nullptr; m->d_temps = nullptr;
     if (m->h_stage) (void)hipHostFree(m->h_stage);
     m->h_stage = nullptr;
     m->num_blocks = 0;
@@ -735,12 +757,13 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->xh, R16 * wide);
     if (!rc) rc = dmalloc(ctx, &m->xl, R16 * wide);
     if (!rc) { HIPCHK(ctx, hipMemsetAsync(m->xh, 0, R16 * wide * 2, ctx->stream)); HIPCHK(ctx, hipMemsetAsync(m->xl, 0, R16 * wide * 2, ctx->stream)); }
-    m->fused_ok = ctx->tp_size == 1 && gemm_rowpar_supported(m->H, m->nh_l * m->hd) && gemm_rowpar_supported(m->H, m->I_l);
-    {
-        const size_t g = std::max<size_t>({(size_t)1, (size_t)gemm_rowpar_groups(m->H, m->nh_l * m->hd), (size_t)gemm_rowpar_groups(m->H, m->I_l)});
-        if (!rc) rc = dmalloc(ctx, &m->ssqA, g * kFusedMaxRows);
-        if (!rc) rc = dmalloc(ctx, &m->ssqB, g * kFusedMaxRows);
-    }
+    if (!rc) rc = dmalloc(ctx, &m->ssqA, (size_t)64 * kFusedMaxRows);  // deferred-norm partials: <= 64 groups
+    if (!rc) rc = dmalloc(ctx, &m->ssqB, (size_t)64 * kFusedMaxRows);
+    if (!rc) rc = dmalloc(ctx, &m->d_keys, (size_t)max_seqs);
+    if (!rc) rc = dmalloc(ctx, &m->d_temps, (size_t)max_seqs);
+    if (!rc) rc = dmalloc(ctx, &m->tickets, (size_t)1024);
+    if (!rc) HIPCHK(ctx, hipMemsetAsync(m->tickets, 0, 1024 * sizeof(unsigned), ctx->stream));
+    if (!rc) rc = dmalloc(ctx, &m->qkv_out, (size_t)std::min<size_t>(R, kFusedMaxRows) * (m->nh_l + 2 * m->kv_l) * m->hd);
     if (!rc) rc = dmalloc(ctx, &m->ctxh, R16 * (size_t)m->nh_l * m->hd);
     if (!rc) rc = dmalloc(ctx, &m->ctxl, R16 * (size_t)m->nh_l * m->hd);
     if (!rc) rc = dmalloc(ctx, &m->xh2, R16 * (size_t)m->I_l);
@@ -838,61 +861,168 @@ extern "C" int nvllm_debug_layer_tap(nvllm_model* m, int layer, int what, float*
 static int tp_reduce(nvllm_model* m, int rows, int ns, const float** in, int* n_slabs) {
     nvllm_ctx* ctx = m->ctx;
     if (ctx->tp_size == 1) { *in = m->slabs; *n_slabs = ns; return NVLLM_OK; }
-    HIPCHK(ctx, launch_slab_sum(m->slabs, ns, (int64_t)rows * m->H, nullptr, rows, m->H, m->red, ctx->stream));
-    int rc_ = comm_allreduce_sum(ctx, m->red, (size_t)rows * m->H);
+    float* buf = m->slabs;  // a single complete partial is reduced where it lies
+    if (ns > 1) {
+        HIPCHK(ctx, launch_slab_sum(m->slabs, ns, (int64_t)rows * m->H, nullptr, rows, m->H, m->red, ctx->stream));
+        buf = m->red;
+    }
+    int rc_ = comm_allreduce_sum(ctx, buf, (size_t)rows * m->H);
     if (rc_) return rc_;
-    *in = m->red;
+    *in = buf;
     *n_slabs = 1;
     return NVLLM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Fused decode forward (tp == 1, R <= kFusedMaxRows): 5 launches per layer instead of 9.
-//   QKV GEMM (slabs) -> attention (q/k-norm + RoPE + KV write in the prologue for single-row tiles)
-//   -> o_proj row-parallel GEMM (+ residual, next-norm prep) -> gate/up GEMM (+ SiLU*mul)
-//   -> down_proj row-parallel GEMM (+ residual, next-norm prep).
-// The two RMSNorm launches per layer disappear: the row-parallel epilogue writes x' = w_next (.) resid and
-// the row's partial sums of squares; every consumer multiplies its (linear) result by rinv[row] (RowNorm).
+// Fused forward (R <= kFusedMaxRows rows: decode steps, short prefill chunks): 5 launches per layer at tp = 1,
+// 7 launches + 2 all-reduces at tp > 1, instead of the generic path's 8..13.
+//   QKV GEMM (complete f32 sums) -> attention (q/k-norm + RoPE + KV write in the prologue for single-row tiles)
+//   -> o_proj -> gate/up GEMM (+ SiLU*mul) -> down_proj.
+//   tp = 1: o_proj / down_proj epilogues add the residual and prepare the next norm (deferred RMSNorm: they write
+//           x' = w_next (.) resid and the row's partial sums of squares; every consumer multiplies its -- linear -- result
+//           by rinv[row], RowNorm), so no norm launch exists.
+//   tp > 1: o_proj / down_proj leave the rank's partial [R, H] f32 in ONE buffer -> all-reduce(sum) in place (the
+//           collective RowParallelLinear::forward lacks, src/layers/linear.rs:184-198) -> one row kernel adds the
+//           residual and prepares the next norm the same deferred way.
+// Each GEMM takes the whole-K register-direct / row-parallel kernel when its shape allows, else the streaming kernel with
+// the matching in-launch-combine epilogue (stream_gemm.hip: 17..64 rows), else -- where slabs are acceptable -- the
+// generic kernel.  fused_plan() says whether every GEMM of the layer has such a form at this row count.
 // ---------------------------------------------------------------------------------------------------
-static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n_last, int logits_row0) {
+enum { G_NONE = 0, G_ROW, G_STREAM, G_GENERIC };
+struct FusedPlan {
+    int qkv = G_NONE, o = G_NONE, gu = G_NONE, down = G_NONE;
+    int packed = 0;  // activation planes in MFMA fragment order between the kernels
+};
+static bool fused_plan(const nvllm_model* m, int R, FusedPlan& p) {
+    const int H = m->H, hd = m->hd, NQ = (m->nh_l + 2 * m->kv_l) * hd, KO = m->nh_l * hd, I2 = 2 * m->I_l;
+    const bool tp = m->ctx->tp_size > 1;
+    if (R > kFusedMaxRows || m->taps || getenv("NVLLM_NO_FUSED")) return false;
+    auto fits = [&](int N, int K, int epi) {
+        return m->opt_stream_combine && gemm_stream_ok(R, N, K, epi) && gemm_stream_slab_floats(R, N, K, epi) <= m->slab_floats;
+    };
+    // QKV: complete sums preferred; the generic kernel's slabs are summed by the attention prologue / qk kernel
+    if (gemm_rowpar_ok(NQ, H, 2, R) && gemm_rowpar_splits(NQ, H, 2, R) == 1) p.qkv = G_ROW;
+    else if (fits(NQ, H, 1)) p.qkv = G_STREAM;
+    else p.qkv = G_GENERIC;
+    // o_proj / down_proj: tp = 1 needs the residual + norm-prep epilogue; tp > 1 one complete partial buffer
+    auto rowlin = [&](int N, int K) -> int {
+        if (!tp) {
+            if (gemm_rowpar_ok(N, K, 0, R) && gemm_rowpar_groups(N, K) <= 64 && gemm_rowpar_groups(N, K) > 0) return G_ROW;
+            if (fits(N, K, 3)) return G_STREAM;
+            return G_NONE;
+        }
+        if (gemm_rowpar_ok(N, K, 2, R) && gemm_rowpar_splits(N, K, 2, R) == 1) return G_ROW;
+        if (fits(N, K, 1)) return G_STREAM;
+        return G_GENERIC;  // slabs + one sum launch before the all-reduce
+    };
+    p.o = rowlin(H, KO);
+    p.down = rowlin(H, m->I_l);
+    if (p.o == G_NONE || p.down == G_NONE) return false;
+    // tp > 1 without a single-buffer kernel for a row-parallel projection: the generic path (streaming slabs + sum) is the
+    // faster one (Qwen3-32B TP=8 shard shapes, per rank: 6.2 vs 7.4 ms/step)
+    if (tp && (p.o == G_GENERIC || p.down == G_GENERIC)) return false;
+    if (gemm_rowpar_ok(I2, H, 1, R)) p.gu = G_ROW;
+    else if (fits(I2, H, 2)) p.gu = G_STREAM;
+    else if (gemm_stream_splits(R, I2, H) > 0) return false;  // big gate/up: streaming slabs + SiLU launch beat the unsplit generic kernel
+    else p.gu = G_GENERIC;  // generic kernel with the SwiGLU epilogue (no K split)
+    static const bool no_xpack = getenv("NVLLM_NO_XPACK") != nullptr;
+    auto takes_packed = [&](int kind, int N, int K, int epi) { return kind == G_STREAM || (kind == G_ROW && gemm_rowdir_ok(N, K, epi, R)); };
+    p.packed = !no_xpack && m->I_l % 32 == 0 && takes_packed(p.qkv, NQ, H, 2) && takes_packed(p.o, H, KO, tp ? 2 : 0) &&
+               takes_packed(p.gu, I2, H, 1) && takes_packed(p.down, H, m->I_l, tp ? 2 : 0);
+    return true;
+}
+
+static int forward_chunk_fused(nvllm_model* m, const FusedPlan& fp, int R, int n_tiles, int qt, int n_last, int logits_row0) {
     nvllm_ctx* ctx = m->ctx;
-    m->stamp_launch = 0;
     hipStream_t s = ctx->stream;
     const int H = m->H, hd = m->hd;
     const float eps = (float)m->cfg.rms_norm_eps;
     const int NQ = (m->nh_l + 2 * m->kv_l) * hd;
     const int KO = m->nh_l * hd;
+    const bool tp = ctx->tp_size > 1;
+    const int packed = fp.packed;
     m->tap_rows = R;
+    m->stamp_launch = 0;
     RowNorm rn;  // the norm pending on xh/xl
     rn.stride = kFusedMaxRows; rn.inv_h = 1.0f / (float)H; rn.eps = eps;
-    // every GEMM of the layer on the register-direct kernel: the activation planes stay in fragment order
-    static const bool no_xpack = getenv("NVLLM_NO_XPACK") != nullptr;
-    const int packed = !no_xpack && gemm_rowdir_ok(NQ, H, 2, R) && gemm_rowdir_ok(H, KO, 0, R) &&
-                       gemm_rowdir_ok(2 * m->I_l, H, 1, R) && gemm_rowdir_ok(H, m->I_l, 0, R);
-    {   // layer 0 input: residual = embedding row, x' = ln1 (.) row, ssq (qwen3.rs:382-386, 465-468)
+    auto stream_args = [&](const bf16_bits* xh, const bf16_bits* xl, int K) {
+        StreamArgs sa;
+        sa.xh = xh; sa.xl = xl; sa.ldx = K; sa.x_packed = packed; sa.M = R; sa.slabs = m->slabs; sa.tickets = m->tickets;
+        return sa;
+    };
+    // prep: resid (+)= in; x' = w (.) resid as hi/lo; ssq[row] (one group).  in == nullptr: layer-0 embedding rows
+    auto prep = [&](const float* in, const float* w, int out_packed) -> int {
         NormArgs na;
-        na.ids = m->d_ids; na.embed = m->embed; na.weight = m->layers[0].ln1; na.eps = eps; na.H = H;
-        na.xh = m->xh; na.xl = m->xl; na.residual_out = m->resid; na.ssq_out = m->ssqB; na.out_packed = packed;
+        if (in) { na.in = in; na.n_slabs = 1; na.residual_in = m->resid; }
+        else { na.ids = m->d_ids; na.embed = m->embed; }
+        na.weight = w; na.eps = eps; na.H = H; na.xh = m->xh; na.xl = m->xl; na.residual_out = m->resid; na.ssq_out = m->ssqB;
+        na.out_packed = out_packed;
         PROF(m, PROF_NORM, launch_add_rmsnorm(na, R, s));
         rn.ssq = m->ssqB; rn.groups = 1;
-    }
+        return NVLLM_OK;
+    };
+    // row-parallel projection (o_proj, down_proj) of input planes (xh_, xl_) [R, K]: tp = 1 epilogue or partial + all-reduce + prep
+    auto row_linear = [&](int kind, const PackedW& w, const bf16_bits* xh_, const bf16_bits* xl_, int K, const float* next_w,
+                          float* ssq_buf, int o_packed) -> int {
+        if (!tp) {
+            if (kind == G_ROW) {
+                RowParArgs ra;
+                ra.xh = xh_; ra.xl = xl_; ra.ldx = K; ra.resid_in = m->resid; ra.resid_out = m->resid; ra.next_w = next_w;
+                ra.oh = m->xh; ra.ol = m->xl; ra.ssq = ssq_buf; ra.ssq_stride = kFusedMaxRows; ra.M = R;
+                ra.x_packed = packed; ra.o_packed = o_packed;
+                STAMPS(ra, m);
+                PROF(m, PROF_GEMM, launch_gemm_rowpar(ra, w, 0, s));
+                rn.ssq = ssq_buf; rn.groups = gemm_rowpar_groups(H, K);
+            } else {
+                StreamArgs sa = stream_args(xh_, xl_, K);
+                sa.resid_in = m->resid; sa.resid_out = m->resid; sa.next_w = next_w; sa.oh = m->xh; sa.ol = m->xl; sa.o_packed = o_packed;
+                sa.ssq = ssq_buf; sa.ssq_stride = kFusedMaxRows;
+                PROF(m, PROF_GEMM, launch_gemm_stream_epi(sa, w, 3, s));
+                rn.ssq = ssq_buf; rn.groups = gemm_stream_groups(R, H, K, 3);
+            }
+            return NVLLM_OK;
+        }
+        if (kind == G_ROW) {
+            RowParArgs ra;
+            ra.xh = xh_; ra.xl = xl_; ra.ldx = K; ra.out = m->red; ra.M = R; ra.x_packed = packed;
+            PROF(m, PROF_GEMM, launch_gemm_rowpar(ra, w, 2, s));
+        } else if (kind == G_STREAM) {
+            StreamArgs sa = stream_args(xh_, xl_, K);
+            sa.out = m->red;
+            PROF(m, PROF_GEMM, launch_gemm_stream_epi(sa, w, 1, s));
+        } else {
+            GemmPlan pg = plan_gemm(R, H, K, 8);
+            PROF(m, PROF_GEMM, launch_gemm(pg, xh_, xl_, K, w, m->slabs, R, s));
+            HIPCHK(ctx, launch_slab_sum(m->slabs, pg.n_split, (int64_t)R * H, nullptr, R, H, m->red, s));
+        }
+        int rc = comm_allreduce_sum(ctx, m->red, (size_t)R * H);
+        if (rc) return rc;
+        return prep(m->red, next_w, o_packed);
+    };
+    // layer 0 input: residual = embedding row, x' = ln1 (.) row, ssq (qwen3.rs:382-386, 465-468)
+    int rc0 = prep(nullptr, m->layers[0].ln1, packed);
+    if (rc0) return rc0;
     for (int l = 0; l < m->L; ++l) {
         const LayerW& w = m->layers[l];
         QkvArgs qa;
-        {   // QKV projection: whole-K row-parallel kernel (one f32 result, no slabs) when the shape allows
+        qa.n_slabs = 1;
+        if (fp.qkv == G_ROW) {
             RowParArgs rq;
             rq.xh = m->xh; rq.xl = m->xl; rq.ldx = H; rq.out = m->slabs; rq.M = R; rq.x_packed = packed;
-            if (gemm_rowpar_ok(NQ, H, 2, R)) {
-                STAMPS(rq, m);
-                PROF(m, PROF_GEMM, launch_gemm_rowpar(rq, w.qkv, 2, s));
-                qa.n_slabs = 1;
-            } else {
-                GemmPlan pq = plan_gemm(R, NQ, H, 8);
-                PROF(m, PROF_GEMM, launch_gemm(pq, m->xh, m->xl, H, w.qkv, m->slabs, R, s));
-                qa.n_slabs = pq.n_split;
-            }
+            STAMPS(rq, m);
+            PROF(m, PROF_GEMM, launch_gemm_rowpar(rq, w.qkv, 2, s));
+            qa.qkv = m->slabs;
+        } else if (fp.qkv == G_STREAM) {
+            StreamArgs sa = stream_args(m->xh, m->xl, H);
+            sa.out = m->qkv_out;
+            PROF(m, PROF_GEMM, launch_gemm_stream_epi(sa, w.qkv, 1, s));
+            qa.qkv = m->qkv_out;
+        } else {
+            GemmPlan pq = plan_gemm(R, NQ, H, 8);
+            PROF(m, PROF_GEMM, launch_gemm(pq, m->xh, m->xl, H, w.qkv, m->slabs, R, s));
+            qa.qkv = m->slabs; qa.n_slabs = pq.n_split;
         }
-        qa.qkv = m->slabs; qa.slab_stride = (int64_t)R * NQ; qa.qn = w.qn; qa.kn = w.kn; qa.eps = eps;
+        qa.slab_stride = (int64_t)R * NQ; qa.qn = w.qn; qa.kn = w.kn; qa.eps = eps;
         qa.cos = m->cosv; qa.sin = m->sinv; qa.pos = m->d_pos; qa.slot = m->d_slot; qa.block_tables = m->d_block_tables;
         qa.max_blocks = m->max_blocks; qa.nh_l = m->nh_l;
         qa.q_scale = powf((float)hd, -0.5f) * 1.4426950408889634f;
@@ -917,36 +1047,29 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
         PROF(m, PROF_EMPTY, hipSuccess);  // calibration: an event pair around nothing, at the attention launch's place
         STAMPS(aa, m);
         PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
-        // o_proj + residual + post-attention norm prep (qwen3.rs:278, :393)
-        RowParArgs ra;
-        ra.xh = m->ctxh; ra.xl = m->ctxl; ra.ldx = KO; ra.resid_in = m->resid; ra.resid_out = m->resid; ra.next_w = w.ln2;
-        ra.oh = m->xh; ra.ol = m->xl; ra.ssq = m->ssqA; ra.ssq_stride = kFusedMaxRows; ra.M = R;
-        ra.x_packed = packed; ra.o_packed = packed;
-        STAMPS(ra, m);
-        PROF(m, PROF_GEMM, launch_gemm_rowpar(ra, w.o, 0, s));
-        rn.ssq = m->ssqA; rn.groups = gemm_rowpar_groups(H, KO);
+        // o_proj (+ residual + post-attention norm prep; qwen3.rs:278, :393)
+        int rc = row_linear(fp.o, w.o, m->ctxh, m->ctxl, KO, w.ln2, m->ssqA, packed);
+        if (rc) return rc;
         // gate/up + SiLU*mul (qwen3.rs:324-325), scaled by the pending norm's rinv
-        {
+        if (fp.gu == G_ROW) {
             RowParArgs rg;
             rg.xh = m->xh; rg.xl = m->xl; rg.ldx = H; rg.oh = m->xh2; rg.ol = m->xl2; rg.M = R; rg.rn = rn;
             rg.x_packed = packed; rg.o_packed = packed;
-            if (gemm_rowpar_ok(2 * m->I_l, H, 1, R)) {
-                STAMPS(rg, m);
-                PROF(m, PROF_GEMM, launch_gemm_rowpar(rg, w.gu, 1, s));
-            } else {
-                GemmPlan pg = plan_gemm_swiglu(R, 2 * m->I_l, H);
-                PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, &rn, s));
-            }
+            STAMPS(rg, m);
+            PROF(m, PROF_GEMM, launch_gemm_rowpar(rg, w.gu, 1, s));
+        } else if (fp.gu == G_STREAM) {
+            StreamArgs sa = stream_args(m->xh, m->xl, H);
+            sa.rn = rn; sa.oh = m->xh2; sa.ol = m->xl2; sa.o_packed = packed;
+            PROF(m, PROF_GEMM, launch_gemm_stream_epi(sa, w.gu, 2, s));
+        } else {
+            GemmPlan pg = plan_gemm_swiglu(R, 2 * m->I_l, H);
+            PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, &rn, s));
         }
-        // down_proj + residual + next layer's input norm prep (qwen3.rs:326, next layer :378; last layer: final norm :497)
-        RowParArgs rd;
-        rd.xh = m->xh2; rd.xl = m->xl2; rd.ldx = m->I_l; rd.resid_in = m->resid; rd.resid_out = m->resid;
-        rd.next_w = l + 1 < m->L ? m->layers[l + 1].ln1 : m->norm;
-        rd.oh = m->xh; rd.ol = m->xl; rd.ssq = m->ssqB; rd.ssq_stride = kFusedMaxRows; rd.M = R;
-        rd.x_packed = packed; rd.o_packed = packed && l + 1 < m->L;  // the LM head (chunked kernel) reads row-major planes
-        STAMPS(rd, m);
-        PROF(m, PROF_GEMM, launch_gemm_rowpar(rd, w.down, 0, s));
-        rn.ssq = m->ssqB; rn.groups = gemm_rowpar_groups(H, m->I_l);
+        // down_proj (+ residual + next layer's input norm prep; qwen3.rs:326, next layer :378; last layer: final norm :497)
+        const bool last = l + 1 == m->L;
+        rc = row_linear(fp.down, w.down, m->xh2, m->xl2, m->I_l, last ? m->norm : m->layers[l + 1].ln1, m->ssqB,
+                        packed && !last);  // the LM head (chunked kernel) reads row-major planes
+        if (rc) return rc;
     }
     if (n_last > 0) {
         // LM head on the last-token rows only (gathered by row_idx), logits scaled by the final norm's rinv
@@ -954,11 +1077,14 @@ static int forward_chunk_fused(nvllm_model* m, int R, int n_tiles, int qt, int n
         float* lg = m->want_logits ? m->logits + (size_t)logits_row0 * m->V_l : nullptr;
         rn.row_idx = m->d_last_rows;
         PROF(m, PROF_LMHEAD, launch_gemm_argmax(pl, m->xh, m->xl, H, m->lm_head, lg, n_last, m->part_val, m->part_idx, &rn, s));
+        const int tps = ctx->tp_size;  // vocab-parallel: every rank leaves (id, max) of its shard for the gather in finish_logits
+        uint32_t* ids_dst = tps == 1 ? m->d_next + logits_row0 : m->d_next + m->cur_n + (size_t)ctx->tp_rank * m->cur_n + logits_row0;
+        float* val_dst = tps == 1 ? nullptr : m->d_maxval + (size_t)ctx->tp_rank * m->cur_n + logits_row0;
         if (pl.lm_nt > 0)
-            HIPCHK(ctx, launch_argmax_rows(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, m->d_next + logits_row0, nullptr, s));
+            HIPCHK(ctx, launch_argmax_rows(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, ids_dst, val_dst, s));
         else
             HIPCHK(ctx, launch_argmax_parts(m->part_val, m->part_idx, gemm_argmax_parts(pl, m->V_l), n_last, m->argmax_scratch,
-                                            m->d_next + logits_row0, nullptr, s));
+                                            ids_dst, val_dst, s));
     }
     return NVLLM_OK;
 }
@@ -994,8 +1120,8 @@ static int gemm_slabs(nvllm_model* m, const bf16_bits* xh, const bf16_bits* xl, 
 
 // rows R (ids/pos/slot/tiles already on the device), n_last rows listed in d_last_rows -> logits rows
 static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last, int logits_row0) {
-    if (m->fused_ok && R <= kFusedMaxRows && !m->taps && !getenv("NVLLM_NO_FUSED"))
-        return forward_chunk_fused(m, R, n_tiles, qt, n_last, logits_row0);
+    FusedPlan fp;
+    if (fused_plan(m, R, fp)) return forward_chunk_fused(m, fp, R, n_tiles, qt, n_last, logits_row0);
     nvllm_ctx* ctx = m->ctx;
     hipStream_t s = ctx->stream;
     const int H = m->H, hd = m->hd;
@@ -1134,6 +1260,7 @@ static void set_attn_split(nvllm_model* m, int n_seqs, int max_len) {
     const int tiles = (max_len + 31) / 32;
     const int base_wgs = std::max(1, n_seqs * m->kv_l);
     int want = std::min(kAttnMaxParts, std::max(1, 512 / base_wgs));
+    if (tiles <= 8) want = 1;  // <= 256 tokens: four waves hold the whole context in one round; a combine launch costs more
     int part = std::max(4, (tiles + want - 1) / want);  // >= 128 tokens per workgroup
     m->attn_part_tiles = part;
     m->attn_parts_max = (tiles + part - 1) / part;
@@ -1232,8 +1359,28 @@ static int upload_chunk(nvllm_model* m, const RowPlan& p, int r0, int R, int t0,
     return NVLLM_OK;
 }
 
+static int step_impl(nvllm_model* m, int n_seqs, const int64_t* seq_ids, const uint32_t* const* tokens, const int32_t* lens,
+                     int is_prefill, uint32_t* next_ids, float* last_logits, const float* temperatures, uint64_t seed);
+
 extern "C" int nvllm_step(nvllm_model* m, int n_seqs, const int64_t* seq_ids, const uint32_t* const* tokens,
                           const int32_t* lens, int is_prefill, uint32_t* next_ids, float* last_logits) {
+    return step_impl(m, n_seqs, seq_ids, tokens, lens, is_prefill, next_ids, last_logits, nullptr, 0);
+}
+
+// per-row key of the sampling counter RNG: (seed, sequence id, position of the token being drawn)
+static inline uint64_t sample_key(uint64_t seed, int64_t seq_id, int len) {
+    return synth_finalize(synth_finalize(seed * 0x9E3779B97F4A7C15ULL + (uint64_t)seq_id) + (uint64_t)len * 0xD1B54A32D192ED03ULL);
+}
+
+extern "C" int nvllm_step_sample(nvllm_model* m, int n_seqs, const int64_t* seq_ids, const uint32_t* const* tokens,
+                                 const int32_t* lens, int is_prefill, const float* temperatures, uint64_t seed,
+                                 uint32_t* next_ids, float* last_logits) {
+    if (m && !temperatures) return fail(m->ctx, NVLLM_EINVAL, "temperatures is NULL");
+    return step_impl(m, n_seqs, seq_ids, tokens, lens, is_prefill, next_ids, last_logits, temperatures, seed);
+}
+
+static int step_impl(nvllm_model* m, int n_seqs, const int64_t* seq_ids, const uint32_t* const* tokens, const int32_t* lens,
+                     int is_prefill, uint32_t* next_ids, float* last_logits, const float* temperatures, uint64_t seed) {
     if (!m) return NVLLM_EINVAL;
     nvllm_ctx* ctx = m->ctx;
     if (!m->finalized) return fail(ctx, NVLLM_ESTATE, "nvllm_model_finalize not called");
@@ -1273,7 +1420,7 @@ extern "C" int nvllm_step(nvllm_model* m, int n_seqs, const int64_t* seq_ids, co
         if (rc) return rc;
     }
     HIPCHK(ctx, hipMemcpyAsync(m->d_block_tables, m->h_block_tables.data(), m->h_block_tables.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    m->want_logits = last_logits != nullptr;
+    m->want_logits = last_logits != nullptr || temperatures != nullptr;  // sampling reads the last-row logits on the device
     m->cur_n = n_seqs;
     set_attn_split(m, n_seqs, *std::max_element(lens, lens + n_seqs));
     // rows and q-tiles
@@ -1316,6 +1463,20 @@ extern "C" int nvllm_step(nvllm_model* m, int n_seqs, const int64_t* seq_ids, co
         if (rc) return rc;
         logits_row += (int)last_local.size();
         r0 += R;
+    }
+    if (temperatures) {
+        // sample_token on the device (llm_engine.rs:97-133): overwrites the greedy ids the LM head's arg-max left.  Under
+        // TP every rank draws over its vocabulary shard with the SAME random stream (indexed by global id); the best
+        // (score, id) pair wins in finish_logits exactly like the greedy (max, id) pair.
+        std::vector<uint64_t> keys(n_seqs);
+        for (int i = 0; i < n_seqs; ++i) keys[i] = sample_key(seed, seq_ids[i], lens[i]);
+        HIPCHK(ctx, hipMemcpyAsync(m->d_keys, keys.data(), (size_t)n_seqs * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(m->d_temps, temperatures, (size_t)n_seqs * 4, hipMemcpyHostToDevice, ctx->stream));
+        const int tps = ctx->tp_size;
+        uint32_t* ids_dst = tps == 1 ? m->d_next : m->d_next + n_seqs + (size_t)ctx->tp_rank * n_seqs;
+        float* val_dst = tps == 1 ? nullptr : m->d_maxval + (size_t)ctx->tp_rank * n_seqs;
+        HIPCHK(ctx, launch_sample_rows(m->logits, n_seqs, m->V_l, m->V_l, m->d_temps, m->d_keys, ctx->tp_rank * m->V_l, ids_dst, val_dst, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // keys / temperatures are read from pageable host memory above
     }
     int rc = finish_logits(m, n_seqs, next_ids, last_logits);
     if (rc) return rc;
@@ -1437,6 +1598,13 @@ extern "C" int64_t nvllm_last_step_bytes(const nvllm_model* m) { return m ? m->l
 // enable != 0 arms the recording for the following steps; read copies launch `launch` of the LAST step:
 // [1024 workgroups][16 waves][8 points] u64 (zero = not written), launches in issue order (QKV, attention, o_proj,
 // gate/up, down per layer).  The product library returns NVLLM_ESTATE.
+// tuning switches of a model (A/B and tests): "stream_combine" = the streaming GEMM's in-launch split-K combine
+extern "C" int nvllm_debug_set_option(nvllm_model* m, const char* name, int value) {
+    if (!m || !name) return NVLLM_EINVAL;
+    if (!strcmp(name, "stream_combine")) { m->opt_stream_combine = value; return NVLLM_OK; }
+    return fail(m->ctx, NVLLM_EINVAL, "unknown option '%s'", name);
+}
+
 extern "C" int nvllm_debug_stamps(nvllm_model* m, int enable) {
     if (!m) return NVLLM_EINVAL;
 #ifdef NVLLM_STAMPS

@@ -1,0 +1,118 @@
+// Device-side helpers shared by the .hip translation units of libnvllm_amd.so (kernels.hip, stream_gemm.hip):
+// MFMA fragment types, bf16 hi/lo split, deferred-RMSNorm helpers, the LDS-DMA publish barrier, diagnostic stamps.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+
+#include "kernels.h"
+
+namespace nvllm {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t bf16_bits_of(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+__device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) {
+    const __bf16 h = (__bf16)x;
+    hi = __builtin_bit_cast(uint16_t, h);
+    lo = __builtin_bit_cast(uint16_t, (__bf16)(x - (float)h));
+}
+__device__ __forceinline__ _Float16 f16_sat(float x) { return (_Float16)fminf(fmaxf(x, -65504.f), 65504.f); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// rinv[row] of a deferred RMSNorm (see RowNorm); 1 when the activations were normalised by the producer
+__device__ __forceinline__ float rownorm_rinv(const RowNorm& rn, int row) {
+    if (!rn.ssq) return 1.0f;
+    float t = 0.f;
+    for (int g = 0; g < rn.groups; ++g) t += rn.ssq[(size_t)g * rn.stride + row];
+    return 1.0f / sqrtf(t * rn.inv_h + rn.eps);
+}
+
+// Workgroup-cooperative form for kernels whose epilogue needs rinv of up to NR rows: every thread sums a
+// strided quarter of the groups of one row with independent (unrollable) loads and parks it in LDS;
+// after any later barrier rownorm_rinv_lds() finishes the sum.  groups <= 64.
+template <int NR>
+__device__ __forceinline__ void rownorm_partials(const RowNorm& rn, int m0, int M, float* lds_part) {
+    if (!rn.ssq) return;
+    // every thread runs the loads (index clamped, only the LDS store is predicated): loads under a divergent branch
+    // are serialised by the compiler, one vmcnt(0) round trip each
+    for (int i0 = 0; i0 < 4 * NR; i0 += blockDim.x) {
+        const int idx = i0 + (int)threadIdx.x;
+        const int ic = min(idx, 4 * NR - 1);
+        const int r = ic % NR, part = ic / NR;
+        int row = min(m0 + r, M - 1);
+        if (rn.row_idx) row = rn.row_idx[row];
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = rn.ssq[(size_t)min(part + 4 * i, rn.groups - 1) * rn.stride + row];
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += (part + 4 * i) < rn.groups ? v[i] : 0.f;
+        if (idx < 4 * NR) lds_part[part * NR + r] = t;
+    }
+}
+template <int NR>
+__device__ __forceinline__ float rownorm_rinv_lds(const RowNorm& rn, const float* lds_part, int r) {
+    if (!rn.ssq) return 1.0f;
+    const float t = lds_part[r] + lds_part[NR + r] + lds_part[2 * NR + r] + lds_part[3 * NR + r];
+    return 1.0f / sqrtf(t * rn.inv_h + rn.eps);
+}
+// one row, one wave: lane g loads group g (groups <= 64)
+__device__ __forceinline__ float rownorm_rinv_wave(const RowNorm& rn, int row, int lane) {
+    if (!rn.ssq) return 1.0f;
+    float t = lane < rn.groups ? rn.ssq[(size_t)lane * rn.stride + row] : 0.f;
+    t = wave_sum(t);
+    return 1.0f / sqrtf(t * rn.inv_h + rn.eps);
+}
+
+// hipFuncSetAttribute is per device: remember on which devices a kernel's dynamic-LDS limit has been raised
+// (one bit per device ordinal; idempotent, so a race between two host threads only repeats the call)
+static inline void ensure_dyn_lds(const void* fn, size_t lds, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        done.fetch_or(bit, std::memory_order_release);
+    }
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Diagnostic build (make stamps, -DNVLLM_STAMPS): in-kernel time stamps of the 100 MHz constant clock, one slot per
+// (workgroup, wave, point); tools/stamp_timeline.py reads them.  Compiled out of the product library.
+#ifdef NVLLM_STAMPS
+#define NVLLM_STAMP(args_, idx_)                                                                                          \
+    do {                                                                                                                  \
+        if ((args_).stamps && (threadIdx.x & 63) == 0)                                                                    \
+            (args_).stamps[(((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * 16 + (threadIdx.x >> 6)) * 8 + (idx_)] = \
+                __builtin_amdgcn_s_memrealtime();                                                                         \
+    } while (0)
+#else
+#define NVLLM_STAMP(args_, idx_) do { } while (0)
+#endif
+
+// Barrier that PUBLISHES LDS-DMA data (global_load_lds): every wave first waits for its own DMA to land, then joins the
+// barrier; only then may any wave ds_read fragments another wave staged.  __syncthreads() alone is not enough: hipcc
+// (ROCm 7.2) emitted the loop-header barrier of gemm_kernel's chunk loop as `s_waitcnt lgkmcnt(0); s_barrier` with
+// the vmcnt(0) AFTER the barrier -- each wave then waits for its own DMA only, and reads of another wave's still-in-
+// flight fragments returned old LDS bytes (no stall, no fault): wrong sums under memory load (several contexts on one
+// GPU), clean on a quiet chip.  The asm wait is invisible to the compiler's waitcnt pass and cannot be moved.
+__device__ __forceinline__ void dma_publish_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+}  // namespace nvllm

@@ -77,6 +77,31 @@ int gemm_stream_splits(int M, int N, int K);
 // x_packed: the planes are in xpack_off order (ldx = K either way)
 hipError_t launch_gemm_stream(const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w, float* out, int M, int x_packed,
                               hipStream_t s);
+// The same kernel with an epilogue on COMPLETE sums (stream_gemm.hip): epi 1 plain f32 [M][N], 2 SwiGLU (w = interleaved
+// gate/up, act hi/lo [M][N/2], input norm rn deferred), 3 residual + next-norm prep (as gemm_rowpar epilogue 0).  K slices
+// combine inside the launch through `slabs` ([gemm_stream_slab_floats] f32 scratch) and `tickets` ([n-groups] unsigned,
+// zero between launches).  Any matrix size; 17..64 rows.
+struct StreamArgs {
+    const bf16_bits* xh = nullptr;
+    const bf16_bits* xl = nullptr;
+    int ldx = 0, x_packed = 0, M = 0;
+    float* slabs = nullptr;
+    unsigned* tickets = nullptr;
+    float* out = nullptr;                                  // epi 1
+    RowNorm rn;                                            // epi 2
+    bf16_bits* oh = nullptr;                               // epi 2: act planes; epi 3: x' planes
+    bf16_bits* ol = nullptr;
+    int o_packed = 0;
+    const float* resid_in = nullptr;                       // epi 3
+    float* resid_out = nullptr;
+    const float* next_w = nullptr;
+    float* ssq = nullptr;                                  // [gemm_stream_groups][ssq_stride]
+    int ssq_stride = 0;
+};
+bool gemm_stream_ok(int M, int N, int K, int epi);
+int gemm_stream_groups(int M, int N, int K, int epi);          // n-groups = tickets needed = ssq groups of epilogue 3
+size_t gemm_stream_slab_floats(int M, int N, int K, int epi);  // f32 scratch the combine needs
+hipError_t launch_gemm_stream_epi(const StreamArgs& a, const PackedW& w, int epi, hipStream_t s);
 // LM head (greedy arg-max epilogue): the streaming kernel for <= 64 rows, else plan_gemm(M, N, K, 1)
 GemmPlan plan_lmhead(int M, int N, int K);
 void set_split(GemmPlan& p, int KT, int want);
@@ -246,6 +271,11 @@ hipError_t launch_split_hilo_pad(const float* x, int rows, int K, int Kpad, bf16
 // argmax with LAST-max tie rule; idx_offset added to the result (vocab-parallel shards)
 hipError_t launch_argmax(const float* logits, int rows, int V, int64_t ld, uint32_t* ids, float* maxval,
                          hipStream_t s);
+// temperature sampling, one row each (llm_engine.rs:97-133): ids[r] = Gumbel-max draw from softmax(logits[r] / max(temps[r], 1e-6)),
+// arg-max (last max) when the weights do not form a distribution; keys[r] seeds row r's counter RNG; idx_offset = first
+// global vocabulary id of this shard (the random stream is indexed by global id); best_score (nullable): the winning score
+hipError_t launch_sample_rows(const float* logits, int rows, int V, int64_t ld, const float* temps, const uint64_t* keys, int idx_offset,
+                              uint32_t* ids, float* best_score, hipStream_t s);
 hipError_t launch_embedding_f32(const float* table, const uint32_t* ids, int n, int V, int H, float* y,
                                 hipStream_t s);
 // fine-seam RoPE on [B,heads,T,hd] f32 in place, positions 0..T

@@ -10,76 +10,10 @@
 #include <atomic>
 #include <cstdlib>
 
+#include "device_common.h"
 #include "synth_device.h"
 
 namespace nvllm {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-// ---------------------------------------------------------------------------------------------------
-// small helpers
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint16_t bf16_bits_of(float x) { return __builtin_bit_cast(uint16_t, (__bf16)x); }
-__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
-__device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) {
-    const __bf16 h = (__bf16)x;
-    hi = __builtin_bit_cast(uint16_t, h);
-    lo = __builtin_bit_cast(uint16_t, (__bf16)(x - (float)h));
-}
-__device__ __forceinline__ _Float16 f16_sat(float x) { return (_Float16)fminf(fmaxf(x, -65504.f), 65504.f); }
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-// rinv[row] of a deferred RMSNorm (see RowNorm); 1 when the activations were normalised by the producer
-__device__ __forceinline__ float rownorm_rinv(const RowNorm& rn, int row) {
-    if (!rn.ssq) return 1.0f;
-    float t = 0.f;
-    for (int g = 0; g < rn.groups; ++g) t += rn.ssq[(size_t)g * rn.stride + row];
-    return 1.0f / sqrtf(t * rn.inv_h + rn.eps);
-}
-
-// Workgroup-cooperative form for kernels whose epilogue needs rinv of up to NR rows: every thread sums a
-// strided quarter of the groups of one row with independent (unrollable) loads and parks it in LDS;
-// after any later barrier rownorm_rinv_lds() finishes the sum.  groups <= 64.
-template <int NR>
-__device__ __forceinline__ void rownorm_partials(const RowNorm& rn, int m0, int M, float* lds_part) {
-    if (!rn.ssq) return;
-    // every thread runs the loads (index clamped, only the LDS store is predicated): loads under a divergent branch
-    // are serialised by the compiler, one vmcnt(0) round trip each
-    for (int i0 = 0; i0 < 4 * NR; i0 += blockDim.x) {
-        const int idx = i0 + (int)threadIdx.x;
-        const int ic = min(idx, 4 * NR - 1);
-        const int r = ic % NR, part = ic / NR;
-        int row = min(m0 + r, M - 1);
-        if (rn.row_idx) row = rn.row_idx[row];
-        float v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = rn.ssq[(size_t)min(part + 4 * i, rn.groups - 1) * rn.stride + row];
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t += (part + 4 * i) < rn.groups ? v[i] : 0.f;
-        if (idx < 4 * NR) lds_part[part * NR + r] = t;
-    }
-}
-template <int NR>
-__device__ __forceinline__ float rownorm_rinv_lds(const RowNorm& rn, const float* lds_part, int r) {
-    if (!rn.ssq) return 1.0f;
-    const float t = lds_part[r] + lds_part[NR + r] + lds_part[2 * NR + r] + lds_part[3 * NR + r];
-    return 1.0f / sqrtf(t * rn.inv_h + rn.eps);
-}
-// one row, one wave: lane g loads group g (groups <= 64)
-__device__ __forceinline__ float rownorm_rinv_wave(const RowNorm& rn, int row, int lane) {
-    if (!rn.ssq) return 1.0f;
-    float t = lane < rn.groups ? rn.ssq[(size_t)lane * rn.stride + row] : 0.f;
-    t = wave_sum(t);
-    return 1.0f / sqrtf(t * rn.inv_h + rn.eps);
-}
 
 // ---------------------------------------------------------------------------------------------------
 // weight packing / synthetic fill
@@ -136,18 +70,6 @@ __global__ void __launch_bounds__(256) synth_rowmajor_f32_kernel(float* __restri
                                                                  int64_t first, int64_t count) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
         dst[i] = bf16_to_f32(synth_bits(name_hash, (uint64_t)(first + i), kind));
-}
-
-// hipFuncSetAttribute is per device: remember on which devices a kernel's dynamic-LDS limit has been raised
-// (one bit per device ordinal; idempotent, so a race between two host threads only repeats the call)
-static inline void ensure_dyn_lds(const void* fn, size_t lds, std::atomic<uint64_t>& done) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const uint64_t bit = 1ull << (dev & 63);
-    if (!(done.load(std::memory_order_acquire) & bit)) {
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        done.fetch_or(bit, std::memory_order_release);
-    }
 }
 
 static inline int grid_for(int64_t n, int per_block = 256, int cap = 8192) {
@@ -227,33 +149,6 @@ hipError_t launch_split_hilo(const float* x, bf16_bits* hi, bf16_bits* lo, int64
 // fragment pair, f32 accumulate: this keeps logits within 1e-3 of the f32 reference.
 // grid = (n-groups, k-splits, m-blocks); k-splits write separate f32 slabs, summed by the consumer.
 // ---------------------------------------------------------------------------------------------------
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// Diagnostic build (make stamps, -DNVLLM_STAMPS): in-kernel time stamps of the 100 MHz constant clock, one slot per
-// (workgroup, wave, point); tools/stamp_timeline.py reads them.  Compiled out of the product library.
-#ifdef NVLLM_STAMPS
-#define NVLLM_STAMP(args_, idx_)                                                                                          \
-    do {                                                                                                                  \
-        if ((args_).stamps && (threadIdx.x & 63) == 0)                                                                    \
-            (args_).stamps[(((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * 16 + (threadIdx.x >> 6)) * 8 + (idx_)] = \
-                __builtin_amdgcn_s_memrealtime();                                                                         \
-    } while (0)
-#else
-#define NVLLM_STAMP(args_, idx_) do { } while (0)
-#endif
-
-// Barrier that PUBLISHES LDS-DMA data (global_load_lds): every wave first waits for its own DMA to land, then joins the
-// barrier; only then may any wave ds_read fragments another wave staged.  __syncthreads() alone is not enough: hipcc
-// (ROCm 7.2) emitted the loop-header barrier of gemm_kernel's chunk loop as `s_waitcnt lgkmcnt(0); s_barrier` with
-// the vmcnt(0) AFTER the barrier -- each wave then waits for its own DMA only, and reads of another wave's still-in-
-// flight fragments returned old LDS bytes (no stall, no fault): wrong sums under memory load (several contexts on one
-// GPU), clean on a quiet chip.  The asm wait is invisible to the compiler's waitcnt pass and cannot be moved.
-__device__ __forceinline__ void dma_publish_barrier() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-}
-
 // MODE 0: f32 slabs.  MODE 1: + per-wave partial arg-max (LM head).  MODE 2: SwiGLU epilogue -- the weight is
 // the gate/up matrix interleaved in 16-row tiles (NT == 2: tile 0 = gate, tile 1 = up of the same 16 features),
 // the wave writes silu(gate)*up as bf16 hi/lo planes act[M][N/2] (SiluAndMul, activation.rs:13-18); no split-K.
@@ -799,161 +694,6 @@ static hipError_t lmhead_launch_t(const bf16_bits* xh, const bf16_bits* xl, int 
     const int waves = (w.N / 16 + NT - 1) / NT;
     lmhead_kernel<MT, NT, NCH><<<(waves + 7) / 8, 512, lds, s>>>(xh, xl, ldx, w.data, out, M, w.N, w.K / 32, part_val, part_idx, rn);
     return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Streaming GEMM for the big decode matrices (>= 24 MB, 17..64 rows: Qwen3-8B/32B layers, TP shards): the
-// lmhead_kernel pipeline with the K range cut into slices over blockIdx.y so that about one workgroup of 8 waves
-// lands on every CU.  A wave owns NT n-tiles over its slice and keeps two SC-k-tile weight sets in flight
-// (NT*SC = 4..6 KiB each); x rides through LDS in 8-k-tile chunks; slice ks leaves the f32 slab out[ks][M][N]
-// (summed by the consumer: add_rmsnorm / silu_mul / attention prologue).  Replaces the phase-stepped
-// gemm_rowpar_kernel<4,8,1,8,PH,2> (2.2-2.7 TB/s on the 8B shapes: four dependent 8 KiB phases per wave).
-// ---------------------------------------------------------------------------------------------------
-template <int NT, int SC>
-__global__ void __launch_bounds__(512) gemm_stream_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, int ldx,
-                                                          const uint4* __restrict__ wp, float* __restrict__ out, int M, int N, int KT,
-                                                          int kts, int x_packed) {
-    constexpr int MT = 4, NW = 8, KC = 8;
-    constexpr int FRAGS = 2 * MT * KC;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    uint4* lds = reinterpret_cast<uint4*>(smem_raw);  // [2][FRAGS][64]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, grp = lane >> 4;
-    const int ntiles = N >> 4;
-    const int nt0 = ((int)blockIdx.x * NW + wave) * NT;
-    const int kt_begin = (int)blockIdx.y * kts;
-    // element offset of this lane's 16 bytes of k-tile (kt_begin + wave), row block b; xstep = one k-tile further.
-    // Row-major planes: 16 rows x 64 B per fragment; packed planes (xpack_off order): one contiguous 1 KiB fragment
-    unsigned xoff[MT];
-    const unsigned xstep = x_packed ? 512u : 32u;
-#pragma unroll
-    for (int b = 0; b < MT; ++b)
-        xoff[b] = x_packed ? (unsigned)((b * (ldx >> 5) + kt_begin + wave) * 512 + lane * 8)
-                           : (unsigned)min(b * 16 + l15, M - 1) * (unsigned)ldx + (unsigned)((kt_begin + wave) * 32 + grp * 8);
-    f32x4 acc[NT][MT];
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto stage = [&](int c, int buf) {
-#pragma unroll
-        for (int plane = 0; plane < 2; ++plane)
-#pragma unroll
-            for (int b = 0; b < MT; ++b) {
-                const uint16_t* src = (plane ? xl : xh) + (size_t)(xoff[b] + (unsigned)(c * KC) * xstep);
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (size_t)(buf * FRAGS + (plane * MT + b) * KC + wave) * 64), 16, 0, 0);
-            }
-    };
-    uint4 wA[NT][SC], wB[NT][SC];
-    auto issue_w = [&](int k_rel, uint4 (&w)[NT][SC]) {
-        const int kt = kt_begin + min(k_rel, kts - SC);  // past the slice: a harmless re-read of its last set
-#pragma unroll
-        for (int a = 0; a < NT; ++a) {
-            const int ntc = min(nt0 + a, ntiles - 1);
-#pragma unroll
-            for (int j = 0; j < SC; ++j) w[a][j] = wp[((size_t)ntc * KT + kt + j) * 64 + lane];
-        }
-    };
-    auto compute = [&](int k0, int buf, const uint4 (&w)[NT][SC]) {
-#pragma unroll
-        for (int j = 0; j < SC; ++j)
-#pragma unroll
-            for (int plane = 0; plane < 2; ++plane) {
-                bf16x8 bx[MT];
-#pragma unroll
-                for (int b = 0; b < MT; ++b)
-                    bx[b] = __builtin_bit_cast(bf16x8, lds[(size_t)(buf * FRAGS + (plane * MT + b) * KC + k0 + j) * 64 + lane]);
-#pragma unroll
-                for (int a = 0; a < NT; ++a) {
-                    const bf16x8 wv = __builtin_bit_cast(bf16x8, w[a][j]);
-#pragma unroll
-                    for (int b = 0; b < MT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, bx[b], acc[a][b], 0, 0, 0);
-                }
-            }
-    };
-    const int nchunks = kts / KC;
-    stage(0, 0);
-    issue_w(0, wA);
-    issue_w(SC, wB);
-    for (int c = 0; c < nchunks; ++c) {
-        // as lmhead_kernel: after the first chunk only this wave's x stage is waited for, the KC/SC weight sets issued
-        // after it stay in flight across the barrier
-        if (c == 0) dma_publish_barrier();
-        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((KC / SC) * NT * SC) : "memory");
-        if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const int base = c * KC, buf = c & 1;
-#define NVLLM_ST_STEP(k0_, set_, next_)            \
-    compute(k0_, buf, set_);                       \
-    __builtin_amdgcn_sched_barrier(0);             \
-    issue_w(next_, set_);                          \
-    __builtin_amdgcn_sched_barrier(0);
-        if constexpr (SC == 4) {
-            NVLLM_ST_STEP(0, wA, base + 8)
-            NVLLM_ST_STEP(4, wB, base + 12)
-        } else {
-            static_assert(SC == 2, "sets of 2 or 4 k-tiles");
-            NVLLM_ST_STEP(0, wA, base + 4)
-            NVLLM_ST_STEP(2, wB, base + 6)
-            NVLLM_ST_STEP(4, wA, base + 8)
-            NVLLM_ST_STEP(6, wB, base + 10)
-        }
-#undef NVLLM_ST_STEP
-    }
-    float* o = out + (size_t)blockIdx.y * (size_t)M * N;
-#pragma unroll
-    for (int a = 0; a < NT; ++a) {
-        if (nt0 + a >= ntiles) continue;
-#pragma unroll
-        for (int b = 0; b < MT; ++b) {
-            const int row = b * 16 + l15;
-            if (row < M) {
-                const f32x4 v = acc[a][b];
-                *reinterpret_cast<float4*>(o + (size_t)row * N + (size_t)(nt0 + a) * 16 + grp * 4) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
-    }
-}
-
-// (NT, K slices) of the streaming GEMM: about one 8-wave workgroup per CU; nt == 0 -> not applicable
-struct StreamShape { int nt, ks; };
-static StreamShape stream_shape(int M, int N, int K) {
-    StreamShape none{0, 0};
-    static const bool off = getenv("NVLLM_NO_STREAM") != nullptr;
-    if (off || M <= 16 || M > 64 || N % 16 || K % 256 || (size_t)N * K * 2 < ((size_t)24 << 20)) return none;
-    const int KT = K / 32, ntiles = N / 16;
-    StreamShape best = none;
-    int best_wgs = 0;
-    for (int nt = 3; nt >= 1; --nt)
-        for (int ks = 1; ks <= 16; ++ks) {
-            if (KT % ks || (KT / ks) % 8 || KT / ks < 16) continue;
-            const int wgs = (((ntiles + nt - 1) / nt + 7) / 8) * ks;
-            // most workgroups within one round of the chip; ties go to fewer slices (fewer slabs for the consumer)
-            if (wgs <= 256 && (wgs > best_wgs || (wgs == best_wgs && ks < best.ks))) { best_wgs = wgs; best = StreamShape{nt, ks}; }
-        }
-    return best_wgs >= 128 ? best : none;
-}
-int gemm_stream_splits(int M, int N, int K) { return stream_shape(M, N, K).ks; }
-
-template <int NT, int SC>
-static hipError_t stream_launch_t(const StreamShape& sh, const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w,
-                                  float* out, int M, int x_packed, hipStream_t s) {
-    const size_t lds = (size_t)2 * (2 * 4 * 8) * 1024;
-    static std::atomic<uint64_t> lds_set{0};
-    ensure_dyn_lds(reinterpret_cast<const void*>(gemm_stream_kernel<NT, SC>), lds, lds_set);
-    const int waves = (w.N / 16 + NT - 1) / NT;
-    dim3 grid((waves + 7) / 8, sh.ks);
-    gemm_stream_kernel<NT, SC><<<grid, 512, lds, s>>>(xh, xl, ldx, w.data, out, M, w.N, w.K / 32, w.K / 32 / sh.ks, x_packed);
-    return hipGetLastError();
-}
-hipError_t launch_gemm_stream(const bf16_bits* xh, const bf16_bits* xl, int ldx, const PackedW& w, float* out, int M, int x_packed,
-                              hipStream_t s) {
-    const StreamShape sh = stream_shape(M, w.N, w.K);
-    if (!sh.nt || ldx != w.K) return hipErrorNotSupported;
-    // set depth made no difference on MI355X (2- vs 4-k-tile sets, tools/probe_lm.py): the shallow ones use fewer registers
-    if (sh.nt == 1) return stream_launch_t<1, 4>(sh, xh, xl, ldx, w, out, M, x_packed, s);
-    if (sh.nt == 2) return stream_launch_t<2, 2>(sh, xh, xl, ldx, w, out, M, x_packed, s);
-    return stream_launch_t<3, 2>(sh, xh, xl, ldx, w, out, M, x_packed, s);
 }
 
 GemmPlan plan_lmhead(int M, int N, int K) {
@@ -2333,9 +2073,31 @@ hipError_t launch_slab_sum(const float* in, int n_slabs, int64_t slab_stride, co
                            float* y, hipStream_t s) {
     return launch_slab_sum_ld(in, n_slabs, slab_stride, N, bias, rows, N, y, N, s);
 }
+// dense case (the TP reduce input): float4 per thread, four slabs per trip with independent loads
+__global__ void __launch_bounds__(256) slab_sum_dense_kernel(const float4* __restrict__ in, int n_slabs, int64_t slab_stride4, int64_t total4,
+                                                             float4* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    float4 v = in[i];
+    for (int sl0 = 1; sl0 < n_slabs; sl0 += 4) {
+        float4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = in[i + (int64_t)min(sl0 + u, n_slabs - 1) * slab_stride4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (sl0 + u < n_slabs) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+    }
+    y[i] = v;
+}
 hipError_t launch_slab_sum_ld(const float* in, int n_slabs, int64_t slab_stride, int64_t ld_in, const float* bias,
                               int rows, int N, float* y, int64_t ld_out, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
+    if (!bias && ld_in == N && ld_out == N && N % 4 == 0 && slab_stride % 4 == 0) {
+        const int64_t total4 = (int64_t)rows * N / 4;
+        slab_sum_dense_kernel<<<(unsigned)((total4 + 255) / 256), 256, 0, s>>>(reinterpret_cast<const float4*>(in), n_slabs, slab_stride / 4, total4,
+                                                                                reinterpret_cast<float4*>(y));
+        return hipGetLastError();
+    }
     slab_sum_kernel<<<grid_for((int64_t)rows * N), 256, 0, s>>>(in, n_slabs, slab_stride, ld_in, bias, rows, N, y, ld_out);
     return hipGetLastError();
 }
@@ -2433,6 +2195,81 @@ hipError_t launch_argmax(const float* logits, int rows, int V, int64_t ld, uint3
                          hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     argmax_kernel<<<rows, 1024, 0, s>>>(logits, V, ld, ids, maxval);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Temperature sampling on the device: Qwen3ModelRunner::sample_token (src/engine/llm_engine.rs:97-133).
+//   t = max(temperature, 1e-6); weights w_i = exp((l_i - max l) / t); categorical draw over w; when the weights do not
+//   form a distribution (sum not finite or not positive) the reference falls back to argmax (last max, :135-142).
+// The draw uses the Gumbel-max form, id = argmax_i (l_i / t + g_i) with g_i = -log(-log(u_i)), which samples exactly
+// softmax(l / t) and needs no prefix sums; u_i comes from a counter RNG keyed by (seed, sequence id, position, i), so a
+// run is reproducible and independent of batch composition (the reference draws from an unseeded thread RNG).
+// Ties go to the higher index, like the arg-max.  One workgroup per row.
+// ---------------------------------------------------------------------------------------------------
+__host__ __device__ inline float sample_u01(uint64_t key, uint32_t i) {
+    const uint64_t x = synth_finalize(key + ((uint64_t)i + 1) * 0x9E3779B97F4A7C15ULL);
+    return ((float)(x >> 40) + 0.5f) * 5.9604644775390625e-08f;  // (0, 1): 24 random bits
+}
+__global__ void __launch_bounds__(1024) sample_rows_kernel(const float* __restrict__ logits, int V, int64_t ld, const float* __restrict__ temps,
+                                                           const uint64_t* __restrict__ keys, int idx_offset, uint32_t* __restrict__ ids,
+                                                           float* __restrict__ best_score) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ float s_max, s_sum;
+    const float* p = logits + (size_t)blockIdx.x * ld;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const float t = fmaxf(temps[blockIdx.x], 1e-6f);
+    // pass 1: max and sum of exp((l - max) / t): does the row form a distribution?
+    float mx = -INFINITY;
+    bool nan = false;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) { const float v = p[i]; nan |= v != v; mx = fmaxf(mx, v); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) sv[wv] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) { float m = sv[0]; for (int w = 1; w < nw; ++w) m = fmaxf(m, sv[w]); s_max = m; }
+    __syncthreads();
+    mx = s_max;
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) sum += expf((p[i] - mx) / t);
+    sum = wave_sum(sum);
+    __syncthreads();
+    if (lane == 0) sv[wv] = nan ? NAN : sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { float s = 0.f; for (int w = 0; w < nw; ++w) s += sv[w]; s_sum = s; }
+    __syncthreads();
+    const bool degenerate = !(s_sum > 0.f) || !(s_sum < INFINITY);
+    // pass 2: arg-max of the Gumbel-perturbed scores (plain logits for a degenerate row): LAST max wins
+    const uint64_t key = keys[blockIdx.x];
+    float bv = -INFINITY;
+    int bi = -1;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        float v = p[i];
+        if (v != v) v = -INFINITY;  // a NaN logit ranks below every number
+        if (!degenerate) v = v / t - logf(-logf(sample_u01(key, (uint32_t)(i + idx_offset))));
+        if (v >= bv || bi < 0) { bv = v; bi = i; }  // i increases per thread: >= keeps the last
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi > bi))) { bv = ov; bi = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { sv[wv] = bv; si[wv] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w)
+            if (si[w] >= 0 && (bi < 0 || sv[w] > bv || (sv[w] == bv && si[w] > bi))) { bv = sv[w]; bi = si[w]; }
+        ids[blockIdx.x] = (uint32_t)(bi < 0 ? 0 : bi);
+        if (best_score) best_score[blockIdx.x] = bv;
+    }
+}
+hipError_t launch_sample_rows(const float* logits, int rows, int V, int64_t ld, const float* temps, const uint64_t* keys, int idx_offset,
+                              uint32_t* ids, float* best_score, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    sample_rows_kernel<<<rows, 1024, 0, s>>>(logits, V, ld, temps, keys, idx_offset, ids, best_score);
     return hipGetLastError();
 }
 

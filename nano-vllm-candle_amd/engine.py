@@ -186,46 +186,78 @@ class ModelRunner:
         raise NotImplementedError
 
 
+_M64 = (1 << 64) - 1
+
+
+def _finalize64(z):
+    """splitmix64 finalizer (csrc/synth_device.h synth_finalize), on Python ints"""
+    z &= _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def sample_key(seed, seq_id, length):
+    """per-row key of the device sampler's counter RNG (csrc/api.cpp sample_key)"""
+    return _finalize64(_finalize64((seed * 0x9E3779B97F4A7C15 + (seq_id & _M64)) & _M64) + length * 0xD1B54A32D192ED03)
+
+
+def sample_token_host(logits_last, temperature, key):
+    """Host mirror of the device sampler (csrc/kernels.hip sample_rows_kernel), itself the reference's sample_token
+    (llm_engine.rs:97-133): t = max(T, 1e-6); weights exp((l - max) / t); a row whose weights do not form a distribution
+    falls back to the last-max arg-max; otherwise the categorical draw in Gumbel-max form over the counter RNG `key`."""
+    l = np.asarray(logits_last, np.float32)
+    t = np.float32(max(float(temperature), 1e-6))
+    with np.errstate(all="ignore"):
+        w = np.exp((l - l.max()) / t, dtype=np.float32)
+        s = w.sum(dtype=np.float32)
+    if not np.isfinite(s) or s <= 0 or np.isnan(l).any():
+        return Qwen3ModelRunner.argmax(np.where(np.isnan(l), -np.inf, l))  # a NaN logit ranks below every number
+    i = np.arange(1, l.size + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(key) + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = ((z >> np.uint64(40)).astype(np.float32) + np.float32(0.5)) * np.float32(5.9604644775390625e-08)
+    score = l / t - np.log(-np.log(u, dtype=np.float32), dtype=np.float32)
+    return int(np.flatnonzero(score == score.max())[-1])
+
+
 class Qwen3ModelRunner(ModelRunner):
     """src/engine/llm_engine.rs:35-189 with the forward replaced by the HIP step.
 
-    greedy=True  -> ids come from the device argmax (the reference's `argmax` rule: last max).
-    greedy=False -> the reference's sample_token: softmax((l-max)/max(T,1e-6)), categorical draw
-                    (llm_engine.rs:97-133) on the host from the returned last-row logits; `rng` may be seeded
-                    (the reference's is not).
+    greedy=False (default, like the reference): every id goes through sample_token -- softmax((l-max)/max(T,1e-6)) and a
+                    categorical draw (llm_engine.rs:97-133) -- on the DEVICE (nvllm_step_sample), seeded per runner
+                    (`seed`; the reference's RNG is unseeded, so a run of the reference is one such seed).
+    greedy=True  -> ids come from the device arg-max (the reference's `argmax` fallback rule: last max).
+    An empty sequence is fed as [eos] (the reference pads rows with eos and reads row 0, llm_engine.rs:80-90,181).
     Errors never propagate: any failure -> eos for every sequence (llm_engine.rs:153-175)."""
 
-    def __init__(self, model, greedy=True, rng=None, raise_errors=False):
+    def __init__(self, model, greedy=False, seed=None, raise_errors=False):
         self.model = model
         self.cfg = model.cfg
         self.eos_id = model.cfg.eos_token_id
         self.greedy = greedy
-        self.rng = rng or np.random.default_rng()
+        self.seed = int.from_bytes(__import__("os").urandom(8), "little") if seed is None else int(seed)
         self.raise_errors = raise_errors
         self.last_error = None
 
     def run(self, seqs, is_prefill):
         if not seqs:
             return []
+        toks = [s.token_ids if s.token_ids else [self.eos_id] for s in seqs]
         try:
-            ids, logits = self.model.step([s.seq_id for s in seqs], [s.token_ids for s in seqs], is_prefill,
-                                          want_logits=not self.greedy)
+            if self.greedy:
+                ids, _ = self.model.step([s.seq_id for s in seqs], toks, is_prefill)
+            else:
+                ids, _ = self.model.step_sample([s.seq_id for s in seqs], toks, is_prefill, [s.temperature for s in seqs], self.seed)
         except Exception as e:  # noqa: BLE001 -- the reference logs and returns eos for all
             if self.raise_errors:
                 raise
             self.last_error = e
             return [self.eos_id] * len(seqs)
-        if self.greedy:
-            return [int(t) for t in ids]
-        return [self.sample_token(logits[i], s) for i, s in enumerate(seqs)]
-
-    def sample_token(self, logits_last, seq):
-        t = np.float32(max(seq.temperature, 1e-6))
-        w = np.exp((logits_last - logits_last.max()) / t, dtype=np.float32)
-        s = w.sum(dtype=np.float32)
-        if not np.isfinite(s) or s <= 0:
-            return self.argmax(logits_last)
-        return int(self.rng.choice(len(w), p=(w / s).astype(np.float64) / float((w / s).astype(np.float64).sum())))
+        return [int(t) for t in ids]
 
     @staticmethod
     def argmax(logits):

@@ -236,6 +236,26 @@ class Qwen3ForCausalLM:
                                          lg.ctypes.data_as(C.POINTER(C.c_float)) if lg is not None else None), self.ctx.h)
         return nxt, lg
 
+    def step_sample(self, seq_ids, token_lists, is_prefill, temperatures, seed, want_logits=False):
+        """ModelRunner::run with sample_token on the device (llm_engine.rs:97-133): -> (sampled ids, last_logits or None)"""
+        n = len(seq_ids)
+        if n == 0:
+            return np.empty(0, np.uint32), None
+        arrs = [np.ascontiguousarray(t, dtype=np.uint32) for t in token_lists]
+        u32p = C.POINTER(C.c_uint32)
+        ptrs = (u32p * n)(*[a.ctypes.data_as(u32p) for a in arrs])
+        lens = (C.c_int32 * n)(*[len(a) for a in arrs])
+        ids = (C.c_int64 * n)(*[int(s) for s in seq_ids])
+        temps = np.ascontiguousarray(temperatures, np.float32)
+        if temps.shape != (n,):
+            raise ValueError("one temperature per sequence")
+        nxt = np.empty(n, np.uint32)
+        lg = np.empty((n, self.cfg.vocab_size), np.float32) if want_logits else None
+        _lib.check(_lib.lib().nvllm_step_sample(self.h, n, ids, ptrs, lens, int(bool(is_prefill)),
+                                                temps.ctypes.data_as(C.POINTER(C.c_float)), int(seed) & (2**64 - 1), nxt.ctypes.data_as(u32p),
+                                                lg.ctypes.data_as(C.POINTER(C.c_float)) if lg is not None else None), self.ctx.h)
+        return nxt, lg
+
     def decode_next(self, want_ids=True):
         n = getattr(self, "max_seqs", 0)
         buf = np.empty(max(n, 1), np.uint32)
@@ -264,6 +284,10 @@ class Qwen3ForCausalLM:
         ms, n = C.c_double(), C.c_int64()
         _lib.check(_lib.lib().nvllm_profile_read(self.h, C.byref(ms), C.byref(n)), self.ctx.h)
         return ms.value, n.value
+
+    def set_option(self, name, value):
+        """tuning switch of the model (include/nvllm_amd_debug.h nvllm_debug_set_option)"""
+        _lib.check(_lib.lib().nvllm_debug_set_option(self.h, name.encode(), int(value)), self.ctx.h)
 
     def enable_taps(self, on=True):
         _lib.check(_lib.lib().nvllm_debug_enable_taps(self.h, int(on)), self.ctx.h)

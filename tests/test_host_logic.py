@@ -172,3 +172,27 @@ def test_hf_tensor_names_match_reference_loader():
               "model.layers.0.mlp.down_proj.weight", "model.layers.1.post_attention_layernorm.weight"):
         assert n in names
     assert len(names) == 3 + 11 * 2
+
+
+# ---- sample_token (src/engine/llm_engine.rs:97-133): host mirror of the device sampler --------------------------
+def test_sampler_mirror_degenerate_rows_fall_back_to_last_max():
+    from nano_vllm_candle_amd.engine import sample_key, sample_token_host
+
+    k = sample_key(1, 2, 3)
+    assert sample_token_host(np.array([0.0, 3.0, 2.9, 1.0], np.float32), 1e-12, k) == 1      # T clamps to 1e-6: the arg-max
+    assert sample_token_host(np.array([1.0, np.nan, 5.0, 5.0], np.float32), 1.0, k) == 3     # NaN weights: no distribution
+    assert sample_token_host(np.array([-np.inf] * 4, np.float32), 1.0, k) == 3               # exp(nan): no distribution
+    assert sample_key(1, 2, 3) == sample_key(1, 2, 3) != sample_key(1, 2, 4)
+
+
+def test_sampler_mirror_draws_from_the_softmax():
+    from nano_vllm_candle_amd.engine import sample_key, sample_token_host
+
+    logits = np.array([2.0, 0.5, -1.0, 1.5, 0.0, -3.0, 1.0, 0.25], np.float32)
+    for temp in (0.7, 1.0, 2.5):
+        p = np.exp((logits - logits.max()) / temp)
+        p /= p.sum()
+        n = 20000
+        counts = np.bincount([sample_token_host(logits, temp, sample_key(7, 11, i)) for i in range(n)], minlength=8)
+        # every class within 4 standard deviations of its binomial expectation
+        assert (np.abs(counts - n * p) <= 4 * np.sqrt(n * p * (1 - p)) + 1).all(), (temp, counts, n * p)

@@ -336,8 +336,8 @@ def test_0_6b_layer_shapes_fused_decode_vs_oracle(pkg, ctx, oracle):
                 s_.append(int(t))
 
 
-@pytest.mark.parametrize("inter", [12288, 2048])
-def test_8b_layer_shapes_streaming_decode_vs_oracle(pkg, ctx, oracle, inter):
+@pytest.mark.parametrize("inter,combine", [(12288, 0), (2048, 0), (12288, 1), (2048, 1)])
+def test_8b_layer_shapes_streaming_decode_vs_oracle(pkg, ctx, oracle, inter, combine):
     # the generic decode path at Qwen3-8B LAYER shapes (H 4096, 32/8 heads of 128, I 12288: every projection is a
     # >= 24 MB matrix -> K-sliced streaming GEMM on packed activation planes + slab-summing consumers) on a 1-layer,
     # 4096-token-vocabulary model: 20 sequences (17..64 rows select the streaming kernel), prefill + 2 decode steps.
@@ -347,6 +347,9 @@ def test_8b_layer_shapes_streaming_decode_vs_oracle(pkg, ctx, oracle, inter):
                                num_attention_heads=32, num_key_value_heads=8, intermediate_size=inter)
     m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
     m.kv_alloc(32, 24, 1024)
+    # combine = 1: the fused forward on the streaming GEMM's in-launch split-K combine epilogues (complete QKV sums,
+    # SwiGLU, residual + next-norm prep) instead of slabs + consumer launches (the default: measured faster)
+    m.set_option("stream_combine", combine)
     om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(0)
     rng = np.random.default_rng(6)
     sids = list(range(20))
@@ -386,3 +389,47 @@ def test_full_size_batch64_properties(pkg, ctx):
     m.step(list(range(64)), prompts, True)
     b = [m.decode_next()[:64].copy() for _ in range(3)]
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_device_sampler_equals_its_host_mirror_and_is_reproducible(pkg, ctx):
+    # sample_token on the device (nvllm_step_sample; llm_engine.rs:97-133): same seed -> the ids the host mirror draws
+    # from the returned last-row logits; the temperature clamp (1e-6) degenerates to the greedy arg-max
+    from nano_vllm_candle_amd.engine import (LLMEngine, Qwen3ModelRunner, SamplingParams, Scheduler, SchedulerConfig, sample_key,
+                                             sample_token_host)
+
+    cfg = pkg.Qwen3Config.tiny()
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 9, ctx)
+    m.kv_alloc(32, 16, 64)  # the prefill-first scheduler admits all five requests at once, beside the five below
+    rng = np.random.default_rng(4)
+    sids = [40, 41, 42, 43, 44]
+    seqs = [rng.integers(3, cfg.vocab_size, n).tolist() for n in (6, 19, 2, 33, 11)]
+    temps = [0.0, 0.7, 1.0, 5.0, 1.3]
+    for seed in (0, 123456789, 2**63 + 5):
+        my = [list(s) for s in seqs]
+        for step in range(4):
+            ids, lg = m.step_sample(sids, my, step == 0, temps, seed, want_logits=True)
+            want = [sample_token_host(lg[i], temps[i], sample_key(seed, sids[i], len(my[i]))) for i in range(len(my))]
+            assert ids.tolist() == want, (seed, step)
+            assert int(ids[0]) == int(np.flatnonzero(lg[0] == lg[0].max())[-1])  # T = 0 clamps to 1e-6: arg-max
+            for s_, t_ in zip(my, ids):
+                s_.append(int(t_))
+    # the engine mirror samples by default, like the reference runner; a seed pins the whole generation
+    def gen(seed):
+        import itertools
+
+        import nano_vllm_candle_amd.engine as E
+
+        E._SEQ_COUNTER = itertools.count(7000)  # the draw is keyed by (seed, seq_id, position): same ids, same run
+        eng = LLMEngine(Scheduler(SchedulerConfig(max_num_seqs=3, eos=cfg.eos_token_id)), Qwen3ModelRunner(m, seed=seed, raise_errors=True))
+        return [t for _, t in eng.generate(seqs, SamplingParams(temperature=1.5, max_tokens=8, ignore_eos=True))]
+
+    a, b, c = gen(5), gen(5), gen(6)
+    assert a == b and a != c
+    # an empty sequence in the batch is served as [eos] (llm_engine.rs:80-90) instead of failing the whole step
+    from nano_vllm_candle_amd.engine import Sequence
+
+    r = Qwen3ModelRunner(m, greedy=True, raise_errors=True)
+    e, f = Sequence([], SamplingParams()), Sequence([5, 6, 7], SamplingParams())
+    out = r.run([e, f], True)
+    alone, _ = m.step([9001], [[cfg.eos_token_id]], True)
+    assert out[0] == int(alone[0]) and r.last_error is None

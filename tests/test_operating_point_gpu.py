@@ -157,7 +157,8 @@ def test_32b_layer_shapes_tp1_vs_oracle(pkg, ctx, oracle):
     m.close()
 
 
-def test_32b_layer_shapes_tp8_shards_vs_oracle(pkg, oracle):
+@pytest.mark.parametrize("n_seqs,combine", [(4, 0), (20, 0), (20, 1)])
+def test_32b_layer_shapes_tp8_shards_vs_oracle(pkg, oracle, n_seqs, combine):
     # the per-rank shapes of Qwen3-32B at TP=8 (8 q heads / 1 kv head per rank, I/8 = 3200 columns, V/8 vocab rows)
     # on ONE GPU through the in-process loopback communicator (one host thread per rank): sharded load, per-rank
     # kernels, the two all-reduces per layer, vocab-parallel ids.  RCCL itself is not exercised (unpinned until
@@ -166,15 +167,17 @@ def test_32b_layer_shapes_tp8_shards_vs_oracle(pkg, oracle):
                                num_attention_heads=64, num_key_value_heads=8, intermediate_size=25600)
     om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(0)
     rng = np.random.default_rng(7)
-    seqs = [rng.integers(0, cfg.vocab_size, int(n)).tolist() for n in (9, 31, 2, 17)]
-    tp, steps = 8, 2
+    # 4 rows: whole-K / generic kernels; 20 rows: the streaming GEMMs (17..64 rows), with slabs or the in-launch combine
+    seqs = [rng.integers(0, cfg.vocab_size, int(n)).tolist() for n in ((9, 31, 2, 17) if n_seqs == 4 else rng.integers(2, 33, n_seqs))]
+    tp, steps = 8, 3
     results, errors = [None] * tp, []
 
     def worker(rank):
         try:
-            c = pkg.Context(0, tp_rank=rank, tp_size=tp, loopback_group="g32b")
+            c = pkg.Context(0, tp_rank=rank, tp_size=tp, loopback_group=f"g32b_{n_seqs}_{combine}")
             mm = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=0, ctx=c)
-            mm.kv_alloc(8, 4, 64)
+            mm.kv_alloc(n_seqs + 4, n_seqs, 1024)
+            mm.set_option("stream_combine", combine)  # 1: streaming GEMMs with the in-launch combine (7 launches per layer)
             my = [list(s) for s in seqs]
             out = []
             for step in range(steps):
