@@ -313,7 +313,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    all_step_tokens = []  # attended tokens of EVERY decode step this process runs (what a rocprofv3 average is taken over)
     for _ in range(a.warmup):
+        all_step_tokens.append(int(ctx_lens.sum()))
         model.decode_next()
         ctx_lens += 1
     barrier()
@@ -330,6 +332,7 @@ def main():
         bytes_total += model.last_step_bytes
         model.decode_collect()
     model.decode_collect()
+    all_step_tokens += [int(ctx_lens.sum()) + i * a.batch for i in range(a.steps)]
     ctx_lens += a.steps
     torch.cuda.synchronize()
     barrier()
@@ -353,6 +356,7 @@ def main():
         for _ in range(pass_steps):
             if kind == "attn":
                 attn_ctx.append(int(ctx_lens.sum()))
+            all_step_tokens.append(int(ctx_lens.sum()))
             model.decode_next()
             ctx_lens += 1
         kern[kind] = model.profile_read()
@@ -417,6 +421,13 @@ def main():
                           "frac": step_gbs / HBM_PEAK_GBS, "bytes_per_step": bytes_total / a.steps,
                           "event_ms_per_step": ev_ms / a.steps},
         "kernel_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
+        # for tools/summarize_prof.py: the attention kernel's algorithmic bytes per launch averaged over ALL decode steps of
+        # this process (warm-up + timed + per-kernel pass) -- the launches a rocprofv3 --stats average covers
+        "all_decode_steps": {"steps": len(all_step_tokens), "attn_algorithmic_bytes_per_launch": float(np.mean(all_step_tokens)) * kv_layer if all_step_tokens else None,
+                             "weight_bytes": {"qkv": 2 * cfg.hidden_size * (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim // tpw,
+                                              "o_proj": 2 * cfg.hidden_size * cfg.num_attention_heads * cfg.head_dim // tpw,
+                                              "gate_up": 4 * cfg.hidden_size * cfg.intermediate_size // tpw,
+                                              "down": 2 * cfg.hidden_size * cfg.intermediate_size // tpw, "lm_head": lm_bytes}},
     }
     out["prefill"] = prefill_info
     if rank == 0 and world == 1 and not a.no_cpu_baseline:  # reported at N=1 only (driver contract)
