@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--prompt-min", type=int, default=64)
     ap.add_argument("--prompt-max", type=int, default=512)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--max-batched-tokens", type=int, default=4096,
+                    help="rows per internal prefill chunk (SchedulerConfig.max_num_batched_tokens, scheduler.rs:10-56: default 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seqs", type=int, default=2, help="sequences of the batch the CPU baseline re-runs")
     ap.add_argument("--profile-steps", type=int, default=8, help="extra steps for the per-kernel HIP-event pass")
@@ -269,7 +271,7 @@ def main():
     total_steps = a.warmup + a.steps + a.profile_steps + 2
     max_len = max(len(p) for p in prompts) + total_steps
     blocks = sum(-(-(len(p) + total_steps) // 256) for p in prompts) + 2
-    model.kv_alloc(num_blocks=blocks, max_seqs=a.batch, max_batched_tokens=4096)
+    model.kv_alloc(num_blocks=blocks, max_seqs=a.batch, max_batched_tokens=a.max_batched_tokens)
     seq_ids = list(range(a.batch))
 
     # prefill (not part of `value`; timed separately for the MFMA-side statement), chunked by max_batched_tokens

@@ -742,11 +742,12 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->d_ids, R);
     if (!rc) rc = dmalloc(ctx, &m->d_pos, R);
     if (!rc) rc = dmalloc(ctx, &m->d_slot, R);
-    if (!rc) rc = dmalloc(ctx, &m->d_tile_row0, R);
-    if (!rc) rc = dmalloc(ctx, &m->d_tile_nrows, R);
-    if (!rc) rc = dmalloc(ctx, &m->d_tile_slot, R);
+    // q-tiles: at most one per row, plus the empty tiles that pad every sequence's list to a multiple of 4 (prefill)
+    if (!rc) rc = dmalloc(ctx, &m->d_tile_row0, 4 * R);
+    if (!rc) rc = dmalloc(ctx, &m->d_tile_nrows, 4 * R);
+    if (!rc) rc = dmalloc(ctx, &m->d_tile_slot, 4 * R);
     if (!rc) rc = dmalloc(ctx, &m->d_last_rows, (size_t)max_seqs);
-    if (!rc) rc = dmalloc(ctx, &m->d_tile_order, R);
+    if (!rc) rc = dmalloc(ctx, &m->d_tile_order, 4 * R);
     if (!rc) rc = dmalloc(ctx, &m->resid, R * m->H);
     if (!rc) rc = dmalloc(ctx, &m->slabs, m->slab_floats);
     if (!rc) rc = dmalloc(ctx, &m->qbuf, R * m->nh_l * m->hd);
@@ -783,7 +784,7 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->argmax_scratch, (size_t)max_seqs + 1);
     if (!rc) HIPCHK(ctx, hipMemsetAsync(m->argmax_scratch, 0, ((size_t)max_seqs + 1) * 8, ctx->stream));
     if (rc) return rc;
-    m->h_stage_bytes = (R * 7 + (size_t)max_seqs * 4) * sizeof(int) + 256;
+    m->h_stage_bytes = (R * 19 + (size_t)max_seqs * 4) * sizeof(int) + 256;
     HIPCHK(ctx, hipHostMalloc(&m->h_stage, m->h_stage_bytes, hipHostMallocDefault));
     // RoPE table: rotary_embedding.rs:56-80 (f32: inv_freq = 1/base^(2j/hd); angle = pos * inv_freq)
     m->rope_len = std::min(m->cfg.max_position_embeddings, m->max_blocks * kBlockTokens);
@@ -1046,7 +1047,8 @@ static int forward_chunk_fused(nvllm_model* m, const FusedPlan& fp, int R, int n
         }
         PROF(m, PROF_EMPTY, hipSuccess);  // calibration: an event pair around nothing, at the attention launch's place
         STAMPS(aa, m);
-        PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
+        if (qt == 2) PROF(m, PROF_ATTN, launch_attn_prefill(aa, n_tiles, s));
+        else PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
         // o_proj (+ residual + post-attention norm prep; qwen3.rs:278, :393)
         int rc = row_linear(fp.o, w.o, m->ctxh, m->ctxl, KO, w.ln2, m->ssqA, packed);
         if (rc) return rc;
@@ -1171,7 +1173,8 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
             aa.part_tiles = m->attn_part_tiles; aa.max_parts = kAttnMaxParts; aa.part_o = m->attn_po; aa.part_ml = m->attn_pml;
             parts_max = m->attn_parts_max;
         }
-        PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
+        if (qt == 2) PROF(m, PROF_ATTN, launch_attn_prefill(aa, n_tiles, s));
+        else PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
         // output projection (qwen3.rs:278) + TP all-reduce
         const int KO = m->nh_l * hd;
         int o_slabs = 1;
@@ -1452,6 +1455,10 @@ static int step_impl(nvllm_model* m, int n_seqs, const int64_t* seq_ids, const u
             int e = r;
             while (e < r0 + R && e - r < tpt && row_seq[e] == row_seq[r]) ++e;
             p.tile_row0.push_back(r); p.tile_nrows.push_back(e - r); p.tile_slot.push_back(p.slot[r]);
+            // prefill attention shares K/V between the four q-tiles of a workgroup: a sequence's tiles start on a multiple
+            // of four, its last group is padded with empty tiles
+            if (qt == 2 && (e == r0 + R || row_seq[e] != row_seq[r]))
+                while (p.tile_row0.size() % kPrefillTileGroup) { p.tile_row0.push_back(r); p.tile_nrows.push_back(0); p.tile_slot.push_back(p.slot[r]); }
             r = e;
         }
         std::vector<int> last_local;
@@ -1803,6 +1810,7 @@ extern "C" int nvllm_op_attention(nvllm_ctx* ctx, const float* q, const float* k
         for (int tt = 0; tt < T; ++tt) { hpos[b * T + tt] = tt; hslot[b * T + tt] = b; }
         for (int j = 0; j < bps; ++j) hbt[b * bps + j] = b * bps + j;
         for (int tt = 0; tt < T; tt += tpt) { ht0.push_back(b * T + tt); htn.push_back(std::min(tpt, T - tt)); hts.push_back(b); }
+        while (ht0.size() % kPrefillTileGroup) { ht0.push_back(b * T); htn.push_back(0); hts.push_back(b); }  // launch_attn_prefill's tile groups
     }
     const int nt = (int)ht0.size();
     HIPCHK(ctx, t.get(&dpos, rows)); HIPCHK(ctx, t.get(&dslot, rows)); HIPCHK(ctx, t.get(&dbt, nblk));
@@ -1820,7 +1828,7 @@ extern "C" int nvllm_op_attention(nvllm_ctx* ctx, const float* q, const float* k
     AttnArgs a;
     a.q = qr; a.kv = kvl; a.block_tables = dbt; a.max_blocks = bps; a.tile_row0 = dt0; a.tile_nrows = dtn; a.tile_slot = dts;
     a.pos = dpos; a.nh_l = nh; a.gqa = gqa; a.out_f32 = out;
-    HIPCHK(ctx, launch_attn_paged(a, nt, qt, rows, 1, s));
+    HIPCHK(ctx, launch_attn_prefill(a, nt, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     return NVLLM_OK;
 }

@@ -212,6 +212,10 @@ struct AttnArgs {
 // qt = q sub-tiles (of 16 MFMA rows) per workgroup: 1 (decode) or 2 (prefill)
 hipError_t launch_attn_paged(const AttnArgs& a, int n_tiles, int qt, int rows, int n_parts_max, hipStream_t s);
 inline int attn_tokens_per_tile(int gqa, int qt) { return (16 / gqa) * qt; }
+// prefill form with LDS-staged K/V shared by four q-tiles (qt = 2) of one sequence: n_tiles is a multiple of 4, tiles
+// 4b..4b+3 belong to one sequence (tile_slot[4b]), a sequence's last group is padded with empty tiles (tile_nrows = 0)
+constexpr int kPrefillTileGroup = 4;
+hipError_t launch_attn_prefill(const AttnArgs& a, int n_tiles, hipStream_t s);
 
 // ---- row-parallel projection with residual + next-norm epilogue (decode, tp == 1) ---------------------
 // resid_out = resid_in + x.W^T ; x' = next_w (.) resid_out as bf16 hi/lo ; ssq[group][row] partial sums of squares.

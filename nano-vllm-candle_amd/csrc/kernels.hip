@@ -1896,6 +1896,176 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
     NVLLM_STAMP(a, 4);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Prefill attention with LDS-staged K/V (same math as attn_paged_kernel, qwen3.rs:236-277).
+// One workgroup = FOUR consecutive q-tiles of ONE sequence (host pads every sequence's tile list to a multiple of four
+// with empty tiles) x one kv head; wave w owns q-tile w for the WHOLE context (no cross-wave combine).  Every 32-token
+// K/V tile is fetched ONCE per workgroup -- 16 KiB by LDS-DMA, 1 KiB per wave-instruction, already in MFMA fragment
+// order so the image is lane-linear -- and read from LDS by the waves that still need it (causal: wave w stops after the
+// tile that holds its last token); the next tile is in flight while the current one is consumed.  The decode kernel,
+// which prefill used before, had every wave fetch its own K/V tiles from global memory: no reuse across q-tiles.
+// ---------------------------------------------------------------------------------------------------
+template <int HD, int QT>
+__global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
+    constexpr int DC = HD / 32, DT = HD / 16, NWV = 4;
+    constexpr int TILE_FRAGS = 2 * DC + DT;  // 1 KiB fragments of one 32-token K/V tile: K lo half, K hi half, V
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint4* lds = reinterpret_cast<uint4*>(smem_raw);  // [2 buffers][TILE_FRAGS][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int kh = blockIdx.y;
+    const int tile = (int)blockIdx.x * NWV + wave;
+    const int slot = a.tile_slot[(int)blockIdx.x * NWV];  // all four tiles belong to one sequence
+    const int row0 = a.tile_row0[tile], nrows = a.tile_nrows[tile];
+    const int gqa = a.gqa, tpq = 16 / gqa;
+    const int kv_l = a.kv.kv_l;
+    const int ldq = a.nh_l * HD;
+    int my_row[QT], my_pos[QT];
+    const int my_head = kh * gqa + (l15 % gqa);
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int tok = t * tpq + l15 / gqa;
+        const bool valid = (l15 < tpq * gqa) && (tok < nrows);
+        my_row[t] = valid ? row0 + tok : -1;
+        my_pos[t] = valid ? a.pos[row0 + tok] : -1;
+    }
+    // tiles this wave needs: up to its last token; tiles the workgroup stages: up to the last token of its last real tile
+    const int my_last = nrows > 0 ? a.pos[row0 + nrows - 1] >> 5 : -1;
+    int wg_last = my_last;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+        const int t2 = (int)blockIdx.x * NWV + w, n2 = a.tile_nrows[t2];
+        if (n2 > 0) wg_last = max(wg_last, a.pos[a.tile_row0[t2] + n2 - 1] >> 5);
+    }
+    if (wg_last < 0) return;  // four empty tiles (uniform)
+    const int* bt = a.block_tables + (size_t)slot * a.max_blocks;
+    const _Float16* kbase = reinterpret_cast<const _Float16*>(a.kv.k);
+    const _Float16* vbase = reinterpret_cast<const _Float16*>(a.kv.v);
+    // stage tile kt into buffer buf: fragment f of the tile goes to wave f % 4 (TILE_FRAGS / 4 DMA loads each)
+    auto stage = [&](int kt, int buf) {
+        const int T0 = kt << 5, blk = bt[T0 >> 8], tb = T0 & 255;
+        const _Float16* kb = kbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 4) * (DC * 512) + lane * 8;
+        const _Float16* vb = vbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 5) * (DT * 512) + lane * 8;
+#pragma unroll
+        for (int i = 0; i < TILE_FRAGS / NWV; ++i) {
+            const int f = wave + i * NWV;
+            const _Float16* src = f < 2 * DC ? kb + f * 512 : vb + (f - 2 * DC) * 512;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (size_t)(buf * TILE_FRAGS + f) * 64), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+    f16x8 qh[QT][DC], ql[QT][DC];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            float x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (my_row[t] >= 0) {
+                const float4* p = reinterpret_cast<const float4*>(a.q + (size_t)my_row[t] * ldq + (size_t)my_head * HD + c * 32 + grp * 8);
+                const float4 u = p[0], w = p[1];
+                x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = w.x; x[5] = w.y; x[6] = w.z; x[7] = w.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 h = (_Float16)x[j];
+                qh[t][c][j] = h;
+                ql[t][c][j] = (_Float16)(x[j] - (float)h);
+            }
+        }
+    f32x4 o[QT][DT];
+    float m[QT], lsum[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m[t] = -1e30f;
+        lsum[t] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int kt = 0; kt <= wg_last; ++kt) {
+        const int buf = kt & 1;
+        dma_publish_barrier();                      // tile kt has landed for every wave; the other buffer is free
+        if (kt + 1 <= wg_last) stage(kt + 1, buf ^ 1);
+        if (kt > my_last) continue;                 // causal: this wave's rows end before this tile (it still stages)
+        const int T0 = kt << 5;
+        const int tokA = T0 + grp * 4, tokB = T0 + 16 + grp * 4;
+        // fragment-outer loops: a K (V) fragment is read from LDS, used for both sub-tiles and dropped, instead of the
+        // whole 16 KiB tile sitting in 64 registers (the difference between one and two waves per SIMD)
+        f32x4 sa[QT], sb[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) { sa[t] = f32x4{0.f, 0.f, 0.f, 0.f}; sb[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            const f16x8 fa = __builtin_bit_cast(f16x8, lds[(size_t)(buf * TILE_FRAGS + c) * 64 + lane]);
+            const f16x8 fb = __builtin_bit_cast(f16x8, lds[(size_t)(buf * TILE_FRAGS + DC + c) * 64 + lane]);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, qh[t][c], sa[t], 0, 0, 0);
+                sa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, ql[t][c], sa[t], 0, 0, 0);
+                sb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, qh[t][c], sb[t], 0, 0, 0);
+                sb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, ql[t][c], sb[t], 0, 0, 0);
+            }
+        }
+        f16x8 P[QT];
+        float alpha[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float mt = -1e30f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (tokA + r <= my_pos[t]) mt = fmaxf(mt, sa[t][r]);
+                if (tokB + r <= my_pos[t]) mt = fmaxf(mt, sb[t][r]);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 16));
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float mn = fmaxf(m[t], mt);
+            alpha[t] = exp2f(m[t] - mn);
+            m[t] = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pa = (tokA + r <= my_pos[t]) ? exp2f(sa[t][r] - mn) : 0.f;
+                const float pb = (tokB + r <= my_pos[t]) ? exp2f(sb[t][r] - mn) : 0.f;
+                ps += pa + pb;
+                P[t][r] = (_Float16)pa;
+                P[t][4 + r] = (_Float16)pb;
+            }
+            lsum[t] = lsum[t] * alpha[t] + ps;
+        }
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            const f16x8 fv = __builtin_bit_cast(f16x8, lds[(size_t)(buf * TILE_FRAGS + 2 * DC + d) * 64 + lane]);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                f32x4 acc = o[t][d];
+                acc[0] *= alpha[t]; acc[1] *= alpha[t]; acc[2] *= alpha[t]; acc[3] *= alpha[t];
+                o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fv, P[t], acc, 0, 0, 0);
+            }
+        }
+    }
+    // every wave owns its rows for the whole context: normalise and store (D[dim 4*grp+reg][q row l15] -> out[row][head dims])
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float l = lsum[t];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        if (my_row[t] < 0) continue;
+        const float inv = 1.0f / l;
+        const size_t base = (size_t)my_row[t] * ldq + (size_t)my_head * HD + grp * 4;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            const float y0 = o[t][d][0] * inv, y1 = o[t][d][1] * inv, y2 = o[t][d][2] * inv, y3 = o[t][d][3] * inv;
+            if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + base + d * 16) = make_float4(y0, y1, y2, y3);
+            if (a.out_hi) {
+                uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
+                split_bf16(y0, h0, l0); split_bf16(y1, h1, l1); split_bf16(y2, h2, l2); split_bf16(y3, h3, l3);
+                const size_t xo = a.out_packed ? xpack_off(my_row[t], my_head * HD + d * 16 + grp * 4, ldq >> 5) : base + d * 16;
+                *reinterpret_cast<uint2*>(a.out_hi + xo) = make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
+                *reinterpret_cast<uint2*>(a.out_lo + xo) = make_uint2(l0 | ((uint32_t)l1 << 16), l2 | ((uint32_t)l3 << 16));
+            }
+        }
+    }
+}
+
 // merge the split-KV partials of one (row, q head): one wave each, lane = 2 (HD 128) or 1 (HD 64) dims
 template <int HD>
 __global__ void __launch_bounds__(256) attn_combine_kernel(AttnArgs a, int rows) {
@@ -1944,6 +2114,21 @@ static hipError_t attn_launch_t(const AttnArgs& a, int n_tiles, int grid_z, hipS
     ensure_dyn_lds(reinterpret_cast<const void*>(attn_paged_kernel<HD, QT, NWV, FUSED>), lds, lds_set);
     dim3 grid(n_tiles, a.kv.kv_l, grid_z);
     attn_paged_kernel<HD, QT, NWV, FUSED><<<grid, NWV * 64, lds, s>>>(a);
+    return hipGetLastError();
+}
+
+// prefill: n_tiles (a multiple of 4: every sequence's tile list padded with empty tiles) q-tiles of 2 sub-tiles each
+hipError_t launch_attn_prefill(const AttnArgs& a, int n_tiles, hipStream_t s) {
+    if (n_tiles <= 0) return hipSuccess;
+    if (n_tiles % 4 || a.gqa < 1 || a.gqa > 16 || (a.kv.hd != 128 && a.kv.hd != 64)) return hipErrorInvalidValue;
+    dim3 grid(n_tiles / 4, a.kv.kv_l);
+    if (a.kv.hd == 128) {
+        const size_t lds = (size_t)2 * (2 * 4 + 8) * 1024;
+        attn_prefill_kernel<128, 2><<<grid, 256, lds, s>>>(a);
+    } else {
+        const size_t lds = (size_t)2 * (2 * 2 + 4) * 1024;
+        attn_prefill_kernel<64, 2><<<grid, 256, lds, s>>>(a);
+    }
     return hipGetLastError();
 }
 
