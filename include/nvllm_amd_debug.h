@@ -53,6 +53,12 @@ int nvllm_debug_gemm_bench(nvllm_ctx* ctx, int M, int N, int K, int nt, int nw, 
 int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int mt, int nt, int nw, int n_split, int mode, int rot,
                             int iters, float* us_per_call);
 
+/* parity + timing of the prefill tile GEMM (256-row x 256/192-feature workgroup tiles, both operands in fragment order)
+ * against the chunked kernel on the same synthetic operands.  mode 0: f32 output; 2: SwiGLU planes (N = 2I), compared as
+ * hi + lo; act_packed: the tile kernel writes its planes in fragment order. */
+int nvllm_debug_gemm_tile_check(nvllm_ctx* ctx, int M, int N, int K, int mode, int act_packed, int iters,
+                                float* max_abs_diff, float* max_abs_ref, float* us_chunked, float* us_tile);
+
 /* tuning aid: time the decode attention (one new token per sequence, ctx_lens[B] cached tokens each) on a
  * synthetic cache; part_tokens > 0 splits every context into workgroups of that many tokens */
 int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int hd, const int32_t* ctx_lens, int part_tokens,

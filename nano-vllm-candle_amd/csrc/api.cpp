@@ -336,6 +336,7 @@ struct nvllm_model {
     // consumer launch on MI355X (Qwen3-8B batch 64: 8.6 vs 6.4 ms/step; 32B TP=8 shard: 8.9 vs 6.5 ms) -- one workgroup
     // per n-group reads every slab behind an agent-scope release of all the others.  nvllm_debug_set_option turns it on.
     int opt_stream_combine = 0;
+    int opt_tile_min_wgs = 192;  // prefill tile GEMM: smallest grid it is used for (256-row tiles need rows to fill 256 CUs)
     unsigned* tickets = nullptr;             // arrival counters of the streaming GEMM's in-launch combine (zero between launches)
     float* qkv_out = nullptr;                // complete QKV sums of the streaming GEMM (its combine reads the slabs in m->slabs)
     uint32_t* d_next = nullptr;
@@ -1137,10 +1138,19 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
     static const bool no_xpack = getenv("NVLLM_NO_XPACK") != nullptr;
     const int packed = !no_xpack && !m->layers.empty() && gemm_streams(m, m->layers[0].qkv, R) && gemm_streams(m, m->layers[0].o, R) &&
                        gemm_streams(m, m->layers[0].gu, R) && gemm_streams(m, m->layers[0].down, R) && m->I_l % 32 == 0;
+    // prompt chunks (MFMA-bound): projections whose grid fills the chip run the tile GEMM (tile_gemm.hip); it reads both
+    // operands in fragment order, so the kernel that produces its input planes writes them that way
+    const int KO = m->nh_l * hd;
+    const int tmin = m->opt_tile_min_wgs;
+    const bool tile_on = !packed && tmin > 0 && R > kFusedMaxRows;
+    const bool t_qkv = tile_on && gemm_tile_ok(R, NQ, H, 0, tmin) && (size_t)R * NQ <= m->slab_floats;
+    const bool t_o = tile_on && gemm_tile_ok(R, H, KO, 0, tmin) && (size_t)R * H <= m->slab_floats;
+    const bool t_gu = tile_on && gemm_tile_ok(R, 2 * m->I_l, H, 2, tmin);
+    const bool t_down = t_gu && m->I_l % 32 == 0 && gemm_tile_ok(R, H, m->I_l, 0, tmin) && (size_t)R * H <= m->slab_floats;
     for (int l = 0; l < m->L; ++l) {
         const LayerW& w = m->layers[l];
         NormArgs na;
-        na.weight = w.ln1; na.eps = eps; na.H = H; na.xh = m->xh; na.xl = m->xl; na.residual_out = m->resid; na.out_packed = packed;
+        na.weight = w.ln1; na.eps = eps; na.H = H; na.xh = m->xh; na.xl = m->xl; na.residual_out = m->resid; na.out_packed = packed || t_qkv;
         if (l == 0) {  // residual None: normed = norm(x), residual = x  (qwen3.rs:382-386)
             na.ids = m->d_ids; na.embed = m->embed;
         } else {       // qwen3.rs:378
@@ -1149,7 +1159,9 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         PROF(m, PROF_NORM, launch_add_rmsnorm(na, R, s));
         // QKV projection (qwen3.rs:205)
         QkvArgs qa;
-        int rcg = gemm_slabs(m, m->xh, m->xl, H, w.qkv, m->slabs, R, 8, &qa.n_slabs, packed);
+        int rcg = NVLLM_OK;
+        if (t_qkv) { PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.qkv, R, 0, m->slabs, nullptr, nullptr, 0, tmin, s)); qa.n_slabs = 1; }
+        else rcg = gemm_slabs(m, m->xh, m->xl, H, w.qkv, m->slabs, R, 8, &qa.n_slabs, packed);
         if (rcg) return rcg;
         qa.qkv = m->slabs; qa.slab_stride = (int64_t)R * NQ; qa.qn = w.qn; qa.kn = w.kn; qa.eps = eps;
         qa.cos = m->cosv; qa.sin = m->sinv; qa.pos = m->d_pos; qa.slot = m->d_slot; qa.block_tables = m->d_block_tables;
@@ -1162,7 +1174,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         AttnArgs aa;
         aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
         aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
-        aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->xh; aa.out_lo = m->xl; aa.out_packed = packed;
+        aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->xh; aa.out_lo = m->xl; aa.out_packed = packed || t_o;
         if (qt == 1) aa.tile_order = m->d_tile_order;
         if (fuse_qk) {
             aa.qkv = qa.qkv; aa.n_slabs = qa.n_slabs; aa.slab_stride = qa.slab_stride; aa.ldqkv = NQ; aa.qn = w.qn; aa.kn = w.kn;
@@ -1176,19 +1188,21 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         if (qt == 2) PROF(m, PROF_ATTN, launch_attn_prefill(aa, n_tiles, s));
         else PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
         // output projection (qwen3.rs:278) + TP all-reduce
-        const int KO = m->nh_l * hd;
         int o_slabs = 1;
-        rcg = gemm_slabs(m, m->xh, m->xl, KO, w.o, m->slabs, R, 8, &o_slabs, packed);
+        if (t_o) PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.o, R, 0, m->slabs, nullptr, nullptr, 0, tmin, s));
+        else rcg = gemm_slabs(m, m->xh, m->xl, KO, w.o, m->slabs, R, 8, &o_slabs, packed);
         if (rcg) return rcg;
         const float* oin; int ons;
         int rc = tp_reduce(m, R, o_slabs, &oin, &ons);
         if (rc) return rc;
         NormArgs nb;  // post-attention add + norm (qwen3.rs:393)
         nb.in = oin; nb.n_slabs = ons; nb.slab_stride = (int64_t)R * H; nb.residual_in = m->resid; nb.residual_out = m->resid;
-        nb.weight = w.ln2; nb.eps = eps; nb.H = H; nb.xh = m->xh; nb.xl = m->xl; nb.out_packed = packed;
+        nb.weight = w.ln2; nb.eps = eps; nb.H = H; nb.xh = m->xh; nb.xl = m->xl; nb.out_packed = packed || t_gu;
         PROF(m, PROF_NORM, launch_add_rmsnorm(nb, R, s));
         // MLP (qwen3.rs:323-327)
-        if (!packed && R <= kFusedMaxRows && gemm_rowpar_ok(2 * m->I_l, H, 1, R)) {
+        if (t_gu) {
+            PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.gu, R, 2, nullptr, m->xh2, m->xl2, t_down ? 1 : 0, tmin, s));
+        } else if (!packed && R <= kFusedMaxRows && gemm_rowpar_ok(2 * m->I_l, H, 1, R)) {
             // small gate/up: whole-K row-parallel kernel with the SiLU*mul epilogue
             RowParArgs rg;
             rg.xh = m->xh; rg.xl = m->xl; rg.ldx = H; rg.oh = m->xh2; rg.ol = m->xl2; rg.M = R;
@@ -1207,7 +1221,8 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
             PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, nullptr, s));
         }
         int d_slabs = 1;
-        rcg = gemm_slabs(m, m->xh2, m->xl2, m->I_l, w.down, m->slabs, R, 8, &d_slabs, packed);
+        if (t_down) PROF(m, PROF_GEMM, launch_gemm_tile(m->xh2, m->xl2, w.down, R, 0, m->slabs, nullptr, nullptr, 0, tmin, s));
+        else rcg = gemm_slabs(m, m->xh2, m->xl2, m->I_l, w.down, m->slabs, R, 8, &d_slabs, packed);
         if (rcg) return rcg;
         rc = tp_reduce(m, R, d_slabs, &prev, &prev_ns);
         if (rc) return rc;
@@ -1605,10 +1620,12 @@ extern "C" int64_t nvllm_last_step_bytes(const nvllm_model* m) { return m ? m->l
 // enable != 0 arms the recording for the following steps; read copies launch `launch` of the LAST step:
 // [1024 workgroups][16 waves][8 points] u64 (zero = not written), launches in issue order (QKV, attention, o_proj,
 // gate/up, down per layer).  The product library returns NVLLM_ESTATE.
-// tuning switches of a model (A/B and tests): "stream_combine" = the streaming GEMM's in-launch split-K combine
+// tuning switches of a model (A/B and tests): "stream_combine" = the streaming GEMM's in-launch split-K combine;
+// "tile_min_wgs" = smallest grid the prefill tile GEMM is used for (1: whenever the shape fits; 0: never)
 extern "C" int nvllm_debug_set_option(nvllm_model* m, const char* name, int value) {
     if (!m || !name) return NVLLM_EINVAL;
     if (!strcmp(name, "stream_combine")) { m->opt_stream_combine = value; return NVLLM_OK; }
+    if (!strcmp(name, "tile_min_wgs")) { m->opt_tile_min_wgs = value; return NVLLM_OK; }  // <= 0: never use the tile GEMM
     return fail(m->ctx, NVLLM_EINVAL, "unknown option '%s'", name);
 }
 
@@ -1900,6 +1917,77 @@ extern "C" int nvllm_debug_gemm_bench(nvllm_ctx* ctx, int M, int N, int K, int n
     float ms = 0;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *us_per_call = ms * 1e3f / iters;
+    return NVLLM_OK;
+}
+
+// parity + timing of the prefill tile GEMM (tile_gemm.hip) against the chunked kernel on the same synthetic operands.
+// mode 0: f32 out; mode 2: SwiGLU planes (compared as hi + lo).  act_packed: the tile kernel writes xpack_off order.
+extern "C" int nvllm_debug_gemm_tile_check(nvllm_ctx* ctx, int M, int N, int K, int mode, int act_packed, int iters,
+                                           float* max_abs_diff, float* max_abs_ref, float* us_chunked, float* us_tile) {
+    if (!ctx || !max_abs_diff || !max_abs_ref || !us_chunked || !us_tile || M < 1 || N % 32 || K % 128 || iters < 1 || (mode != 0 && mode != 2))
+        return fail(ctx, NVLLM_EINVAL, "bad gemm_tile_check arguments");
+    if (!gemm_tile_ok(M, N, K, mode, 1)) return fail(ctx, NVLLM_EINVAL, "no tile shape for M=%d N=%d K=%d mode=%d", M, N, K, mode);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    TmpBufs t;
+    PackedW w; w.N = N; w.K = K;
+    const size_t Mp = (size_t)(M + 15) / 16 * 16;
+    const int No = mode == 2 ? N / 2 : N;
+    bf16_bits *xh, *xl, *ph, *pl, *ah0, *al0, *ah1, *al1; float *o0, *o1;
+    HIPCHK(ctx, t.get(&w.data, (size_t)N * K / 8));
+    HIPCHK(ctx, t.get(&xh, Mp * K)); HIPCHK(ctx, t.get(&xl, Mp * K)); HIPCHK(ctx, t.get(&ph, Mp * K)); HIPCHK(ctx, t.get(&pl, Mp * K));
+    HIPCHK(ctx, t.get(&ah0, Mp * No)); HIPCHK(ctx, t.get(&al0, Mp * No)); HIPCHK(ctx, t.get(&ah1, Mp * No)); HIPCHK(ctx, t.get(&al1, Mp * No));
+    HIPCHK(ctx, t.get(&o0, (size_t)M * N)); HIPCHK(ctx, t.get(&o1, (size_t)M * N));
+    HIPCHK(ctx, launch_synth_packed(w, 0, N, 4321, 0, 0, K, -1, s));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(xh, 777, kSynthMatrix, 0, (int64_t)M * K, s));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(xl, 778, kSynthMatrix, 0, (int64_t)M * K, s));
+    HIPCHK(ctx, launch_xpack_plane(xh, ph, M, K, s));
+    HIPCHK(ctx, launch_xpack_plane(xl, pl, M, K, s));
+    HIPCHK(ctx, hipMemsetAsync(ah1, 0, Mp * No * 2, s)); HIPCHK(ctx, hipMemsetAsync(al1, 0, Mp * No * 2, s));
+    GemmPlan p = mode == 2 ? plan_gemm_swiglu(M, N, K) : plan_gemm(M, N, K, 1);
+    auto old_go = [&]() { return mode == 2 ? launch_gemm_swiglu(p, xh, xl, K, w, M, ah0, al0, nullptr, s) : launch_gemm(p, xh, xl, K, w, o0, M, s); };
+    auto new_go = [&]() { return launch_gemm_tile(ph, pl, w, M, mode, o1, ah1, al1, act_packed, 1, s); };
+    float ms = 0;
+    for (int i = 0; i < 2; ++i) HIPCHK(ctx, old_go());
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(ctx, old_go());
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *us_chunked = ms * 1e3f / iters;
+    for (int i = 0; i < 2; ++i) HIPCHK(ctx, new_go());
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(ctx, new_go());
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *us_tile = ms * 1e3f / iters;
+    double md = 0, mr = 0;
+    if (mode == 0) {
+        std::vector<float> a((size_t)M * N), b((size_t)M * N);
+        HIPCHK(ctx, hipMemcpy(a.data(), o0, a.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(b.data(), o1, b.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < a.size(); ++i) {
+            const double d = std::fabs((double)a[i] - (double)b[i]);
+            md = (d > md || d != d) ? d : md;
+            mr = std::max(mr, std::fabs((double)a[i]));
+        }
+    } else {
+        std::vector<uint16_t> h0(Mp * No), l0(Mp * No), h1(Mp * No), l1(Mp * No);
+        HIPCHK(ctx, hipMemcpy(h0.data(), ah0, h0.size() * 2, hipMemcpyDeviceToHost)); HIPCHK(ctx, hipMemcpy(l0.data(), al0, l0.size() * 2, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(h1.data(), ah1, h1.size() * 2, hipMemcpyDeviceToHost)); HIPCHK(ctx, hipMemcpy(l1.data(), al1, l1.size() * 2, hipMemcpyDeviceToHost));
+        auto f = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float v; memcpy(&v, &u, 4); return (double)v; };
+        for (int r = 0; r < M; ++r)
+            for (int c = 0; c < No; ++c) {
+                const size_t i0 = (size_t)r * No + c, i1 = act_packed ? xpack_off(r, c, No >> 5) : i0;
+                const double a = f(h0[i0]) + f(l0[i0]), b = f(h1[i1]) + f(l1[i1]);
+                const double d = std::fabs(a - b);
+                md = (d > md || d != d) ? d : md;
+                mr = std::max(mr, std::fabs(a));
+            }
+    }
+    *max_abs_diff = (float)md;
+    *max_abs_ref = (float)mr;
     return NVLLM_OK;
 }
 

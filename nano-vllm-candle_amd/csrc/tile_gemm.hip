@@ -1,0 +1,288 @@
+// Prefill GEMM for gfx950: out[M][N] = x[M][K] . W[N][K]^T with x as bf16 hi + lo planes
+// (replaces candle_nn::Linear::forward on prompt chunks: src/layers/linear.rs:35-36,72-77,184-198 via
+//  src/models/qwen3.rs:205 (QKV), :278 (o_proj), :324-326 (gate/up + SiluAndMul, down)).
+//
+// MFMA-bound shape (hundreds to thousands of rows), so the design is about operand reuse and keeping the matrix
+// pipe fed, not about HBM:
+//   * one workgroup = 256 rows x 32*NTW features, 8 waves as 4 (rows) x 2 (features): a wave owns 64 rows x 16*NTW
+//     features = 4 x NTW accumulator tiles (128 registers at NTW = 8), two waves per SIMD;
+//   * BOTH operands are already in MFMA fragment order in HBM (W: PackedW; x: xpack_off planes written by the
+//     producing kernel), so every stage is plain 1 KiB LDS-DMA wave-copies into a lane-linear image: no swizzle,
+//     no ds_write, no bank conflicts, and each W fragment read from LDS feeds 8 MFMAs (4 row tiles x hi/lo), each
+//     x fragment NTW;
+//   * K advances one 32-deep k-tile per stage through a ring of three LDS stages: the DMA of stage s+2 is issued
+//     right after the barrier that opens stage s, so it has a whole stage of MFMAs (64 per wave) to land; ONE
+//     barrier per stage.  Inside a stage the fragments of the next sub-step (and, in the last one, the first
+//     fragments of stage s+1, which the opening barrier already published) are read while the current MFMAs run.
+//   * workgroups that share an XCD (blockIdx % 8) share their x rows or their W features (host picks), so the
+//     operand re-reads hit that XCD's L2.
+// MODE 0: f32 [M][N].  MODE 2: W is the gate/up matrix interleaved in 16-row tiles; the epilogue writes
+// silu(gate)*up as hi/lo planes [M][N/2] (row-major or xpack_off order) -- SiluAndMul, activation.rs:13-18.
+#include <algorithm>
+
+#include "device_common.h"
+#include "kernels.h"
+
+namespace nvllm {
+
+struct TileArgs {
+    const uint4* xh = nullptr;  // packed planes [ceil(M/16)][KT][64] uint4
+    const uint4* xl = nullptr;
+    const uint4* wp = nullptr;  // [N/16][KT][64] uint4
+    float* out = nullptr;       // MODE 0
+    uint16_t* act_hi = nullptr; // MODE 2
+    uint16_t* act_lo = nullptr;
+    int act_packed = 0;
+    int M = 0, N = 0, KT = 0;
+    int MB = 0, NB = 0;         // 256-row blocks, 32*NTW-feature blocks
+    int map = 0;                // 0: id -> (nb fastest); 1: blocks of one XCD share rows; 2: share features
+};
+
+template <int NTW, int MODE>
+__global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
+    constexpr int FR = 2 * NTW + 32;       // 1 KiB fragments per stage: 2*NTW of W, then [plane][16 row tiles] of x
+    constexpr int NI = (FR + 7) / 8;       // DMA wave-copies per wave per stage
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint4* lds = reinterpret_cast<uint4*>(smem_raw);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: DMA sources / LDS targets stay scalar
+    const int l15 = lane & 15, grp = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int KT = a.KT;
+
+    // workgroup -> (row block, feature block); blockIdx % 8 labels the workgroups that land on one XCD
+    int mb, nb;
+    {
+        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+        if (a.map == 1) { nb = slot % a.NB; mb = (slot / a.NB) * 8 + xcd; }
+        else if (a.map == 2) { mb = slot % a.MB; nb = (slot / a.MB) * 8 + xcd; }
+        else { nb = id % a.NB; mb = id / a.NB; }
+        if (mb >= a.MB || nb >= a.NB) return;  // whole workgroup, before any barrier
+    }
+    const int mtiles = (a.M + 15) >> 4;
+
+    // DMA sources of this wave's copies at k-tile 0, without the lane part (advance: 64 uint4 per k-tile).  Row tiles
+    // past the end are clamped to the last one: their products land in columns of D that are never stored.
+    const uint4* src[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int f = min(wave + 8 * i, FR - 1);
+        if (f < 2 * NTW) {
+            src[i] = a.wp + ((size_t)(nb * 2 * NTW + f) * KT) * 64;
+        } else {
+            const int g = f - 2 * NTW, plane = g >> 4, mt = min(mb * 16 + (g & 15), mtiles - 1);
+            src[i] = (plane ? a.xl : a.xh) + ((size_t)mt * KT) * 64;
+        }
+    }
+    // k-tile s (clamped: the two issues past the end re-fetch the last k-tile into a stage nobody reads, so the
+    // stage body has no branch) -> LDS stage `buf`
+    auto issue = [&](int s, int buf) {
+        const size_t koff = (size_t)min(s, KT - 1) * 64;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int f = wave + 8 * i;
+            if (FR % 8 == 0 || f < FR)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + koff + lane), (lptr_t)(lds + (size_t)(buf * FR + f) * 64), 16, 0, 0);
+        }
+    };
+    // LDS byte addresses this lane reads in the three stages: W fragments of this wave's features, x fragments of its
+    // rows.  The fragment reads are inline asm with hand-counted lgkmcnt waits: left to hipcc (ROCm 7.2) every wait in
+    // this loop came out as lgkmcnt(0), i.e. each sub-step also waited for the reads it had just issued for the next one.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem_raw;
+    uint32_t w_cur = lds0 + (uint32_t)((wn * NTW) * 64 + lane) * 16;
+    uint32_t x_cur = lds0 + (uint32_t)((2 * NTW + wm * 4) * 64 + lane) * 16;
+    uint32_t w_nxt = w_cur + FR * 1024, x_nxt = x_cur + FR * 1024, w_fre = w_cur + 2 * FR * 1024, x_fre = x_cur + 2 * FR * 1024;
+    int fre = 2, cur_i = 0, nxt_i = 1;  // stage indices (scalar) for the DMA targets
+#define NVLLM_LDSR(DST_, ADDR_, OFF_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST_) : "v"(ADDR_), "n"(OFF_))
+#define NVLLM_WF(DST_, P_, J_) NVLLM_LDSR(DST_, P_, (J_) * 1024)
+#define NVLLM_XF(DST_, P_, PL_, MT_) NVLLM_LDSR(DST_, P_, ((PL_) * 16 + (MT_)) * 1024)
+#define NVLLM_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N_) : "memory")
+
+    f32x4 acc[NTW][4];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[j][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // every wave waits for its own DMA, then the barrier publishes all of them (and says: the stage read two
+    // barriers ago is free).  One asm statement: the compiler can neither split it nor move LDS reads across it.
+    auto publish = [&]() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    issue(0, 0);
+    issue(1, 1);
+    publish();
+    bf16x8 WA[NTW], WB[NTW], xh0, xl0, xh1, xl1;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) NVLLM_WF(WA[j], w_cur, j);
+    NVLLM_XF(xh0, x_cur, 0, 0);
+    NVLLM_XF(xl0, x_cur, 1, 0);
+
+#define NVLLM_SB __builtin_amdgcn_sched_barrier(0)
+#define NVLLM_TILE_MFMA_HALF(W_, X_, MT_)                                                                    \
+    do {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < NTW; ++j)                                                      \
+            acc[j][MT_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W_[j], X_, acc[j][MT_], 0, 0, 0);          \
+    } while (0)
+    // One stage = k-tile s: Wc (registers) x the four row tiles of this wave; Wn <- W fragments of stage s+1.
+    // Each sub-step: issue the reads of the NEXT sub-step, wait until only those are outstanding (LDS returns in
+    // order), run this sub-step's 2*NTW MFMAs; the sched_barriers keep the MFMAs on their side of the waits.
+    // The DMA of stage s+2 is issued between the hi and lo MFMA groups of the first sub-step (its scalar address
+    // arithmetic issues in the shadow of the MFMAs instead of between the barrier and the first MFMA).
+    constexpr int W1 = NTW / 3, W2 = 2 * NTW / 3;
+#define NVLLM_TILE_STAGE(Wc_, Wn_, S_)                                                                       \
+    do {                                                                                                     \
+        publish();                                                                                           \
+        NVLLM_XF(xh1, x_cur, 0, 1); NVLLM_XF(xl1, x_cur, 1, 1);                                              \
+        _Pragma("unroll") for (int j = 0; j < W1; ++j) NVLLM_WF(Wn_[j], w_nxt, j);                           \
+        NVLLM_LGKM(2 + W1);                                                                                  \
+        NVLLM_SB;                                                                                            \
+        NVLLM_TILE_MFMA_HALF(Wc_, xh0, 0);                                                                   \
+        issue((S_) + 2, fre);                                                                                \
+        NVLLM_TILE_MFMA_HALF(Wc_, xl0, 0);                                                                   \
+        NVLLM_SB;                                                                                            \
+        NVLLM_XF(xh0, x_cur, 0, 2); NVLLM_XF(xl0, x_cur, 1, 2);                                              \
+        _Pragma("unroll") for (int j = W1; j < W2; ++j) NVLLM_WF(Wn_[j], w_nxt, j);                          \
+        NVLLM_LGKM(2 + W2 - W1);                                                                             \
+        NVLLM_SB;                                                                                            \
+        NVLLM_TILE_MFMA_HALF(Wc_, xh1, 1); NVLLM_TILE_MFMA_HALF(Wc_, xl1, 1);                                \
+        NVLLM_SB;                                                                                            \
+        NVLLM_XF(xh1, x_cur, 0, 3); NVLLM_XF(xl1, x_cur, 1, 3);                                              \
+        _Pragma("unroll") for (int j = W2; j < NTW; ++j) NVLLM_WF(Wn_[j], w_nxt, j);                         \
+        NVLLM_LGKM(2 + NTW - W2);                                                                            \
+        NVLLM_SB;                                                                                            \
+        NVLLM_TILE_MFMA_HALF(Wc_, xh0, 2); NVLLM_TILE_MFMA_HALF(Wc_, xl0, 2);                                \
+        NVLLM_SB;                                                                                            \
+        NVLLM_XF(xh0, x_nxt, 0, 0); NVLLM_XF(xl0, x_nxt, 1, 0);                                              \
+        NVLLM_LGKM(2);                                                                                       \
+        NVLLM_SB;                                                                                            \
+        NVLLM_TILE_MFMA_HALF(Wc_, xh1, 3); NVLLM_TILE_MFMA_HALF(Wc_, xl1, 3);                                \
+        NVLLM_SB;                                                                                            \
+        { const uint32_t t_ = w_cur; w_cur = w_nxt; w_nxt = w_fre; w_fre = t_; }                             \
+        { const uint32_t t_ = x_cur; x_cur = x_nxt; x_nxt = x_fre; x_fre = t_; }                             \
+        { const int t_ = cur_i; cur_i = nxt_i; nxt_i = fre; fre = t_; }                                      \
+    } while (0)
+
+    for (int s = 0; s < KT; s += 2) {  // KT is even (host)
+        NVLLM_TILE_STAGE(WA, WB, s);
+        NVLLM_TILE_STAGE(WB, WA, s + 1);
+    }
+#undef NVLLM_TILE_STAGE
+#undef NVLLM_TILE_MFMA_HALF
+#undef NVLLM_SB
+#undef NVLLM_WF
+#undef NVLLM_XF
+#undef NVLLM_LDSR
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the two issues past the end, the last prefetch reads
+#undef NVLLM_LGKM
+
+    // D[feature 4*grp + r][token l15]
+    const int nt0 = nb * 2 * NTW + wn * NTW;
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int row = mb * 256 + wm * 64 + b * 16 + l15;
+            if (row < a.M) {
+                float* o = a.out + (size_t)row * a.N + (size_t)nt0 * 16 + grp * 4;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const f32x4 v = acc[j][b];
+                    *reinterpret_cast<float4*>(o + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    } else {
+        static_assert(MODE != 2 || NTW % 2 == 0, "gate and up tiles of a feature live in one wave");
+        const int I = a.N >> 1;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int row = mb * 256 + wm * 64 + b * 16 + l15;
+            if (row < a.M) {
+#pragma unroll
+                for (int pr = 0; pr < NTW / 2; ++pr) {
+                    const int f0 = ((nt0 >> 1) + pr) * 16 + grp * 4;
+                    uint16_t h[4], l[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float g = acc[2 * pr][b][r], u = acc[2 * pr + 1][b][r];
+                        split_bf16((g / (1.0f + __expf(-g))) * u, h[r], l[r]);
+                    }
+                    const size_t xo = a.act_packed ? xpack_off(row, f0, I >> 5) : (size_t)row * I + f0;
+                    *reinterpret_cast<uint2*>(a.act_hi + xo) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+                    *reinterpret_cast<uint2*>(a.act_lo + xo) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+                }
+            }
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+// Features per wave (NTW) for an [M][N] output: the candidate (8 -> 256-wide, 6 -> 192-wide blocks) that needs the
+// fewest chip rounds x block width; 0 = shape not covered / too few workgroups to be worth it.
+static int tile_ntw(int M, int N, int K, int mode, int min_wgs) {
+    if (M < 1 || K % 64 != 0 || K < 128 || N % 32 != 0) return 0;
+    const int MB = (M + 255) / 256;
+    int best = 0;
+    int64_t best_cost = 0;
+    for (int ntw : {8, 6}) {
+        if (N % (32 * ntw) != 0) continue;
+        if (mode == 2 && ntw % 2) continue;
+        const int64_t wgs = (int64_t)MB * (N / (32 * ntw));
+        if (wgs < min_wgs) continue;
+        const int64_t cost = ((wgs + 255) / 256) * ntw;
+        if (!best || cost < best_cost) { best = ntw; best_cost = cost; }
+    }
+    return best;
+}
+
+bool gemm_tile_ok(int M, int N, int K, int mode, int min_wgs) { return tile_ntw(M, N, K, mode, min_wgs) != 0; }
+
+template <int NTW, int MODE>
+static hipError_t tile_launch_t(TileArgs& a, hipStream_t s) {
+    a.NB = a.N / (32 * NTW);
+    a.MB = (a.M + 255) / 256;
+    int grid;
+    if (a.MB >= 8) { a.map = 1; grid = ((a.MB + 7) / 8) * 8 * a.NB; }
+    else if (a.NB >= 8) { a.map = 2; grid = ((a.NB + 7) / 8) * 8 * a.MB; }
+    else { a.map = 0; grid = a.MB * a.NB; }
+    const size_t lds = (size_t)3 * (2 * NTW + 32) * 1024;
+    static std::atomic<uint64_t> lds_set{0};
+    ensure_dyn_lds(reinterpret_cast<const void*>(gemm_tile_kernel<NTW, MODE>), lds, lds_set);
+    gemm_tile_kernel<NTW, MODE><<<grid, 512, lds, s>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_tile(const bf16_bits* xh, const bf16_bits* xl, const PackedW& w, int M, int mode, float* out,
+                            bf16_bits* act_hi, bf16_bits* act_lo, int act_packed, int min_wgs, hipStream_t s) {
+    const int ntw = tile_ntw(M, w.N, w.K, mode, min_wgs);
+    if (!ntw) return hipErrorNotSupported;
+    if (mode == 2 && act_packed && (w.N / 2) % 32 != 0) return hipErrorNotSupported;
+    TileArgs a;
+    a.xh = reinterpret_cast<const uint4*>(xh); a.xl = reinterpret_cast<const uint4*>(xl); a.wp = w.data;
+    a.out = out; a.act_hi = act_hi; a.act_lo = act_lo; a.act_packed = act_packed;
+    a.M = M; a.N = w.N; a.KT = w.K / 32;
+    if (mode == 0) return ntw == 8 ? tile_launch_t<8, 0>(a, s) : tile_launch_t<6, 0>(a, s);
+    if (mode == 2) return ntw == 8 ? tile_launch_t<8, 2>(a, s) : tile_launch_t<6, 2>(a, s);
+    return hipErrorInvalidValue;
+}
+
+// row-major plane [M][K] -> xpack_off order (tests and the tuning bench; the product's producers write the order directly)
+__global__ void __launch_bounds__(256) xpack_plane_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int M, int K) {
+    const int KT = K >> 5;
+    const int64_t n = (int64_t)((M + 15) >> 4) * KT * 64;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        const int64_t t = i >> 6;
+        const int kt = (int)(t % KT), mt = (int)(t / KT);
+        const int row = min(mt * 16 + (lane & 15), M - 1);
+        dst[i] = src[((size_t)row * K + (size_t)kt * 32 + (lane >> 4) * 8) >> 3];
+    }
+}
+hipError_t launch_xpack_plane(const bf16_bits* src, bf16_bits* dst, int M, int K, hipStream_t s) {
+    if (K % 32 != 0 || M < 1) return hipErrorInvalidValue;
+    const int64_t n = (int64_t)((M + 15) / 16) * (K / 32) * 64;
+    xpack_plane_kernel<<<(int)std::min<int64_t>((n + 255) / 256, 8192), 256, 0, s>>>(reinterpret_cast<const uint4*>(src),
+                                                                                      reinterpret_cast<uint4*>(dst), M, K);
+    return hipGetLastError();
+}
+
+}  // namespace nvllm

@@ -71,13 +71,14 @@ def test_missing_library_raises(monkeypatch, tmp_path):
 
 
 def _kernel_resources():
-    path = os.path.join(ROOT, "nano-vllm-candle_amd", "kernel_resources.txt")
-    if not os.path.exists(path):
-        pytest.skip("kernel_resources.txt missing: rebuild kernels.o (make -C nano-vllm-candle_amd/csrc)")
     out = {}
-    for blk in open(path).read().split("Function Name: ")[1:]:
-        lines = blk.strip().splitlines()
-        out[lines[0].strip()] = {k.strip(): int(v) for k, v in (l.split(":", 1) for l in lines[1:])}
+    for name in ("kernel_resources.txt", "kernel_resources_tile.txt"):
+        path = os.path.join(ROOT, "nano-vllm-candle_amd", name)
+        if not os.path.exists(path):
+            pytest.skip(name + " missing: rebuild the library (make -C nano-vllm-candle_amd/csrc)")
+        for blk in open(path).read().split("Function Name: ")[1:]:
+            lines = blk.strip().splitlines()
+            out[lines[0].strip()] = {k.strip(): int(v) for k, v in (l.split(":", 1) for l in lines[1:])}
     return out
 
 
@@ -95,6 +96,8 @@ def test_hot_kernels_keep_their_register_budget():
         "_ZN5nvllm18gemm_rowdir_kernelILi6ELi16ELi2ELi1EEE": 4,   # gate/up    (N 6144, K 1024)
         "_ZN5nvllm18gemm_rowdir_kernelILi1ELi16ELi6ELi0EEE": 4,   # down_proj  (N 1024, K 3072)
         "_ZN5nvllm13lmhead_kernelILi4ELi5ELi4EEE": 2,             # LM head, 64 rows, vocabulary 151936, K 1024
+        "_ZN5nvllm16gemm_tile_kernelILi8ELi0EEE": 2,              # prefill tile GEMM: 8-wave workgroups, two waves per SIMD
+        "_ZN5nvllm16gemm_tile_kernelILi6ELi2EEE": 2,
     }
     for prefix, min_waves in want.items():
         hits = [(n, r) for n, r in res.items() if n.startswith(prefix)]

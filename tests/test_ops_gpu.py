@@ -230,3 +230,27 @@ def test_device_generator_matches_oracle_generator(Ly, oracle):
         pkg._lib.check(pkg._lib.lib().nvllm_op_synth_bf16(ctx.h, name.encode(), 7, kind, 12345, out.size,
                                                           out.ctypes.data_as(C.POINTER(C.c_uint16))), ctx.h)
         assert np.array_equal(out, oracle.synth_bf16(name, 7, kind, 12345, out.size))
+
+
+@pytest.mark.parametrize("M,N,K,mode,packed", [
+    (4096, 4096, 1024, 0, 0),    # Qwen3-0.6B QKV on a full prompt chunk: one workgroup per CU
+    (4090, 6144, 1024, 2, 0),    # gate/up + SiLU*mul, ragged last row tile, 192-wide blocks, row-major planes out
+    (1000, 6144, 1024, 2, 1),    # few row blocks (feature-major XCD map), planes out in fragment order
+    (300, 1024, 3072, 0, 0),     # down_proj shape, two row blocks, plain workgroup map
+    (513, 512, 128, 0, 0),       # shortest K: four stages
+])
+def test_prefill_tile_gemm_equals_the_chunked_kernel(Ly, M, N, K, mode, packed):
+    # tile_gemm.hip (256-row workgroup tiles, both operands in fragment order, three-stage LDS ring) against the chunked
+    # kernel (which test_linear_vs_oracle pins to the oracle) on the same synthetic operands.  Both accumulate k-tiles in
+    # ascending order, hi then lo, in f32, so the results are equal to the last bit; a published-too-early LDS stage or
+    # a wrong fragment shows as a large difference, not as rounding.
+    import ctypes as C
+
+    from nano_vllm_candle_amd import _lib
+    from nano_vllm_candle_amd import layers
+
+    ctx = layers.default_context()
+    d, r, u0, u1 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+    _lib.check(_lib.lib().nvllm_debug_gemm_tile_check(ctx.h, M, N, K, mode, packed, 2, C.byref(d), C.byref(r), C.byref(u0), C.byref(u1)), ctx.h)
+    assert r.value > 0
+    assert d.value <= 1e-6 * r.value, (d.value, r.value)
