@@ -336,6 +336,7 @@ struct nvllm_model {
     // consumer launch on MI355X (Qwen3-8B batch 64: 8.6 vs 6.4 ms/step; 32B TP=8 shard: 8.9 vs 6.5 ms) -- one workgroup
     // per n-group reads every slab behind an agent-scope release of all the others.  nvllm_debug_set_option turns it on.
     int opt_stream_combine = 0;
+    int opt_tile_fuse_qk = 1;    // QKV tile GEMM with the q/k-norm + RoPE + KV-write epilogue (head_dim 128, 256-wide blocks)
     int opt_tile_min_wgs = 192;  // prefill tile GEMM: smallest grid it is used for (256-row tiles need rows to fill 256 CUs)
     unsigned* tickets = nullptr;             // arrival counters of the streaming GEMM's in-launch combine (zero between launches)
     float* qkv_out = nullptr;                // complete QKV sums of the streaming GEMM (its combine reads the slabs in m->slabs)
@@ -1144,6 +1145,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
     const int tmin = m->opt_tile_min_wgs;
     const bool tile_on = !packed && tmin > 0 && R > kFusedMaxRows;
     const bool t_qkv = tile_on && gemm_tile_ok(R, NQ, H, 0, tmin) && (size_t)R * NQ <= m->slab_floats;
+    const bool t_qkv_fused = t_qkv && m->opt_tile_fuse_qk && gemm_tile_qkv_ok(R, NQ, H, hd, tmin);
     const bool t_o = tile_on && gemm_tile_ok(R, H, KO, 0, tmin) && (size_t)R * H <= m->slab_floats;
     const bool t_gu = tile_on && gemm_tile_ok(R, 2 * m->I_l, H, 2, tmin);
     const bool t_down = t_gu && m->I_l % 32 == 0 && gemm_tile_ok(R, H, m->I_l, 0, tmin) && (size_t)R * H <= m->slab_floats;
@@ -1159,10 +1161,6 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         PROF(m, PROF_NORM, launch_add_rmsnorm(na, R, s));
         // QKV projection (qwen3.rs:205)
         QkvArgs qa;
-        int rcg = NVLLM_OK;
-        if (t_qkv) { PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.qkv, R, 0, m->slabs, nullptr, nullptr, 0, tmin, s)); qa.n_slabs = 1; }
-        else rcg = gemm_slabs(m, m->xh, m->xl, H, w.qkv, m->slabs, R, 8, &qa.n_slabs, packed);
-        if (rcg) return rcg;
         qa.qkv = m->slabs; qa.slab_stride = (int64_t)R * NQ; qa.qn = w.qn; qa.kn = w.kn; qa.eps = eps;
         qa.cos = m->cosv; qa.sin = m->sinv; qa.pos = m->d_pos; qa.slot = m->d_slot; qa.block_tables = m->d_block_tables;
         qa.max_blocks = m->max_blocks; qa.nh_l = m->nh_l;
@@ -1170,7 +1168,16 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         qa.q_out = m->qbuf;
         qa.kv.k = m->kcache[l]; qa.kv.v = m->vcache[l]; qa.kv.kv_l = m->kv_l; qa.kv.hd = hd;
         const bool fuse_qk = qt == 1 && n_tiles == R;  // decode: every q-tile is one row
-        if (!fuse_qk) PROF(m, PROF_QK, launch_qk_norm_rope_kvwrite(qa, R, s));
+        int rcg = NVLLM_OK;
+        if (t_qkv_fused && !fuse_qk) {
+            // prompt chunk: q/k-norm + RoPE + KV write + q output in the QKV GEMM's epilogue (one wave tile = one head)
+            PROF(m, PROF_GEMM, launch_gemm_tile_qkv(m->xh, m->xl, w.qkv, R, qa, tmin, s));
+        } else {
+            if (t_qkv) { PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.qkv, R, 0, m->slabs, nullptr, nullptr, 0, tmin, s)); qa.n_slabs = 1; }
+            else rcg = gemm_slabs(m, m->xh, m->xl, H, w.qkv, m->slabs, R, 8, &qa.n_slabs, packed);
+            if (rcg) return rcg;
+            if (!fuse_qk) PROF(m, PROF_QK, launch_qk_norm_rope_kvwrite(qa, R, s));
+        }
         AttnArgs aa;
         aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
         aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
@@ -1625,6 +1632,7 @@ extern "C" int64_t nvllm_last_step_bytes(const nvllm_model* m) { return m ? m->l
 extern "C" int nvllm_debug_set_option(nvllm_model* m, const char* name, int value) {
     if (!m || !name) return NVLLM_EINVAL;
     if (!strcmp(name, "stream_combine")) { m->opt_stream_combine = value; return NVLLM_OK; }
+    if (!strcmp(name, "tile_fuse_qk")) { m->opt_tile_fuse_qk = value; return NVLLM_OK; }
     if (!strcmp(name, "tile_min_wgs")) { m->opt_tile_min_wgs = value; return NVLLM_OK; }  // <= 0: never use the tile GEMM
     return fail(m->ctx, NVLLM_EINVAL, "unknown option '%s'", name);
 }

@@ -88,6 +88,22 @@ static inline void ensure_dyn_lds(const void* fn, size_t lds, std::atomic<uint64
     }
 }
 
+// KV-cache element offsets inside one (block, kv head) slab of kBlockTokens x hd f16:
+// V in PV A-fragment order: token tt (0..31) of a 32-token tile sits in k-slot (g, j): tt<16: g=tt>>2, j=tt&3;
+//   else g=(tt-16)>>2, j=4+(tt&3); element (tt, d) -> (((tile*(hd/16) + d/16)*64 + g*16 + d%16)*8 + j
+// K in QK^T A-fragment order: 16-token tiles, each hd/32 chunks of 1 KiB: lane (g*16 + r) holds token r, dims 32c+8g..+7
+__device__ __forceinline__ size_t k_packed_offset(int t_in_block, int d, int hd) {
+    const int tt = t_in_block >> 4, r = t_in_block & 15;
+    const int c = d >> 5, g = (d & 31) >> 3, j = d & 7;
+    return ((size_t)(tt * (hd >> 5) + c) * 64 + (g << 4) + r) * 8 + j;
+}
+
+__device__ __forceinline__ size_t v_packed_offset(int t_in_block, int d, int hd) {
+    const int tile = t_in_block >> 5, tt = t_in_block & 31;
+    const int g = (tt & 15) >> 2, j = ((tt >> 4) << 2) | (tt & 3);
+    return ((size_t)(tile * (hd >> 4) + (d >> 4)) * 64 + (g << 4) + (d & 15)) * 8 + j;
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 

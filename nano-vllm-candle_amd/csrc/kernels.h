@@ -11,16 +11,6 @@ typedef uint16_t f16_bits;   // raw f16 storage
 
 constexpr int kBlockTokens = 256;  // KV block size, fixed by the reference (src/engine/sequence.rs:35)
 
-// ---- prefill GEMM (tile_gemm.hip): 256 x 256/192 output tile, both operands in fragment order -------------------
-// x planes in xpack_off order; mode 0: out f32 [M][N]; mode 2: w = interleaved gate/up, act hi/lo [M][N/2] (row-major or
-// xpack_off order).  min_wgs: smallest grid the kernel is used for (a 256-row tile needs many rows to fill 256 CUs).
-// hipErrorNotSupported = shape not covered.
-struct PackedW;
-bool gemm_tile_ok(int M, int N, int K, int mode, int min_wgs);
-hipError_t launch_gemm_tile(const bf16_bits* xh, const bf16_bits* xl, const PackedW& w, int M, int mode, float* out,
-                            bf16_bits* act_hi, bf16_bits* act_lo, int act_packed, int min_wgs, hipStream_t s);
-hipError_t launch_xpack_plane(const bf16_bits* src, bf16_bits* dst, int M, int K, hipStream_t s);
-
 // ---- packed weight: MFMA 16x16x32 A-fragment tiles -------------------------------------------
 // W[N][K] (row-major, bf16) is stored as [N/16][K/32][64 lanes][8 bf16]; lane l of tile (nt,kt)
 // holds W[nt*16 + (l&15)][kt*32 + 8*(l>>4) + 0..7].  One wave-load = one contiguous 1 KiB tile.
@@ -180,6 +170,20 @@ struct QkvArgs {
     RowNorm rn;                  // deferred input norm (qkv sums are multiplied by rinv[row] first)
 };
 hipError_t launch_qk_norm_rope_kvwrite(const QkvArgs& a, int rows, hipStream_t s);
+
+// ---- prefill GEMM (tile_gemm.hip): 256 x 256/192 output tile, both operands in fragment order -------------------
+// x planes in xpack_off order; mode 0: out f32 [M][N]; mode 2: w = interleaved gate/up, act hi/lo [M][N/2] (row-major or
+// xpack_off order).  min_wgs: smallest grid the kernel is used for (a 256-row tile needs many rows to fill 256 CUs).
+// hipErrorNotSupported = shape not covered.
+bool gemm_tile_ok(int M, int N, int K, int mode, int min_wgs);
+hipError_t launch_gemm_tile(const bf16_bits* xh, const bf16_bits* xl, const PackedW& w, int M, int mode, float* out,
+                            bf16_bits* act_hi, bf16_bits* act_lo, int act_packed, int min_wgs, hipStream_t s);
+// mode 3 = the QKV projection of a prompt chunk with q/k-norm + RoPE + KV-cache write + q output in the epilogue
+// (qwen3.rs:205-234): needs 256-wide blocks and head_dim 128 (one wave tile = one head); qa.qkv is ignored.
+bool gemm_tile_qkv_ok(int M, int N, int K, int hd, int min_wgs);
+hipError_t launch_gemm_tile_qkv(const bf16_bits* xh, const bf16_bits* xl, const PackedW& w, int M, const QkvArgs& qa, int min_wgs,
+                                hipStream_t s);
+hipError_t launch_xpack_plane(const bf16_bits* src, bf16_bits* dst, int M, int K, hipStream_t s);
 
 // ---- paged attention (prefill tiles and decode rows alike) ----------------------------------------
 struct AttnArgs {

@@ -18,6 +18,11 @@
 //     operand re-reads hit that XCD's L2.
 // MODE 0: f32 [M][N].  MODE 2: W is the gate/up matrix interleaved in 16-row tiles; the epilogue writes
 // silu(gate)*up as hi/lo planes [M][N/2] (row-major or xpack_off order) -- SiluAndMul, activation.rs:13-18.
+// MODE 3 (NTW = 8, head_dim 128): W is the fused QKV matrix, so a wave's 64 rows x 128 features are 64 tokens of ONE
+// head and the epilogue is the whole of qwen3.rs:208-234 on registers: RMS norm over the head (q_norm / k_norm BEFORE
+// RoPE), half-split RoPE (rotary_embedding.rs:82-107: features d and d+64 sit in the same lane, accumulators j and j+4),
+// then q (scaled) to the f32 q buffer, K and V as f16 into the paged cache in their fragment orders.  No f32 QKV
+// round trip through HBM and no separate row kernel.
 #include <algorithm>
 
 #include "device_common.h"
@@ -36,6 +41,7 @@ struct TileArgs {
     int M = 0, N = 0, KT = 0;
     int MB = 0, NB = 0;         // 256-row blocks, 32*NTW-feature blocks
     int map = 0;                // 0: id -> (nb fastest); 1: blocks of one XCD share rows; 2: share features
+    QkvArgs q;                  // MODE 3
 };
 
 template <int NTW, int MODE>
@@ -190,6 +196,73 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
                 }
             }
         }
+    } else if constexpr (MODE == 3) {
+        static_assert(MODE != 3 || NTW == 8, "one wave tile = one 128-wide head");
+        const QkvArgs& q = a.q;
+        const int hh = nb * 2 + wn;  // this wave's head: [q heads | k heads | v heads]
+        const int nh = q.nh_l, kvl = q.kv.kv_l;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int row = mb * 256 + wm * 64 + b * 16 + l15;
+            const int rowc = min(row, a.M - 1);
+            const int pos = q.pos[rowc];
+            const float ri = rownorm_rinv(q.rn, rowc);  // deferred input norm (1 when the planes were normalised)
+            if (hh < nh + kvl) {
+                float ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = acc[j][b][r] * ri;
+                        acc[j][b][r] = x;
+                        ss += x * x;
+                    }
+                ss += __shfl_xor(ss, 16);  // the four lane groups hold the other 96 features of this token
+                ss += __shfl_xor(ss, 32);
+                const float rinv = 1.0f / sqrtf(ss / 128.0f + q.eps);
+                const float* w = hh < nh ? q.qn : q.kn;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int d = j * 16 + grp * 4;
+                    const float4 w1 = *reinterpret_cast<const float4*>(w + d), w2 = *reinterpret_cast<const float4*>(w + 64 + d);
+                    const float4 cs = *reinterpret_cast<const float4*>(q.cos + (size_t)pos * 64 + d);
+                    const float4 sn = *reinterpret_cast<const float4*>(q.sin + (size_t)pos * 64 + d);
+                    const float w1a[4] = {w1.x, w1.y, w1.z, w1.w}, w2a[4] = {w2.x, w2.y, w2.z, w2.w};
+                    const float ca[4] = {cs.x, cs.y, cs.z, cs.w}, sa[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float n1 = (acc[j][b][r] * rinv) * w1a[r], n2 = (acc[j + 4][b][r] * rinv) * w2a[r];
+                        acc[j][b][r] = n1 * ca[r] - n2 * sa[r];
+                        acc[j + 4][b][r] = n2 * ca[r] + n1 * sa[r];
+                    }
+                }
+                if (row < a.M) {
+                    if (hh < nh) {
+                        float* qo = q.q_out + (size_t)row * (nh * 128) + (size_t)hh * 128 + grp * 4;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            *reinterpret_cast<float4*>(qo + j * 16) = make_float4(acc[j][b][0] * q.q_scale, acc[j][b][1] * q.q_scale,
+                                                                                 acc[j][b][2] * q.q_scale, acc[j][b][3] * q.q_scale);
+                    } else {
+                        const int blk = q.block_tables[(size_t)q.slot[row] * q.max_blocks + (pos >> 8)];
+                        _Float16* k = reinterpret_cast<_Float16*>(q.kv.k) + (size_t)(blk * kvl + (hh - nh)) * kBlockTokens * 128;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+                            const f16x4 v = {f16_sat(acc[j][b][0]), f16_sat(acc[j][b][1]), f16_sat(acc[j][b][2]), f16_sat(acc[j][b][3])};
+                            *reinterpret_cast<f16x4*>(k + k_packed_offset(pos & 255, j * 16 + grp * 4, 128)) = v;
+                        }
+                    }
+                }
+            } else if (row < a.M) {  // V head: plain copy into the PV fragment order (tokens are the fast index there)
+                const int blk = q.block_tables[(size_t)q.slot[row] * q.max_blocks + (pos >> 8)];
+                _Float16* v = reinterpret_cast<_Float16*>(q.kv.v) + (size_t)(blk * kvl + (hh - nh - kvl)) * kBlockTokens * 128;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[v_packed_offset(pos & 255, j * 16 + grp * 4 + r, 128)] = f16_sat(acc[j][b][r] * ri);
+            }
+        }
     } else {
         static_assert(MODE != 2 || NTW % 2 == 0, "gate and up tiles of a feature live in one wave");
         const int I = a.N >> 1;
@@ -263,6 +336,18 @@ hipError_t launch_gemm_tile(const bf16_bits* xh, const bf16_bits* xl, const Pack
     if (mode == 0) return ntw == 8 ? tile_launch_t<8, 0>(a, s) : tile_launch_t<6, 0>(a, s);
     if (mode == 2) return ntw == 8 ? tile_launch_t<8, 2>(a, s) : tile_launch_t<6, 2>(a, s);
     return hipErrorInvalidValue;
+}
+
+bool gemm_tile_qkv_ok(int M, int N, int K, int hd, int min_wgs) { return hd == 128 && tile_ntw(M, N, K, 0, min_wgs) == 8; }
+
+hipError_t launch_gemm_tile_qkv(const bf16_bits* xh, const bf16_bits* xl, const PackedW& w, int M, const QkvArgs& qa, int min_wgs,
+                                hipStream_t s) {
+    if (!gemm_tile_qkv_ok(M, w.N, w.K, qa.kv.hd, min_wgs) || w.N != (qa.nh_l + 2 * qa.kv.kv_l) * 128) return hipErrorNotSupported;
+    if (qa.rn.ssq && qa.rn.groups != 1) return hipErrorNotSupported;
+    TileArgs a;
+    a.xh = reinterpret_cast<const uint4*>(xh); a.xl = reinterpret_cast<const uint4*>(xl); a.wp = w.data;
+    a.M = M; a.N = w.N; a.KT = w.K / 32; a.q = qa;
+    return tile_launch_t<8, 3>(a, s);
 }
 
 // row-major plane [M][K] -> xpack_off order (tests and the tuning bench; the product's producers write the order directly)

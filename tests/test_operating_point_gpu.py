@@ -72,22 +72,25 @@ def test_0_6b_full_depth_long_contexts_vs_oracle(pkg, ctx, oracle_0_6b):
     m.close()
 
 
-def test_0_6b_full_depth_prefill_through_the_tile_gemm_vs_oracle(pkg, ctx, oracle_0_6b):
+@pytest.mark.parametrize("fuse_qk", [1, 0])
+def test_0_6b_full_depth_prefill_through_the_tile_gemm_vs_oracle(pkg, ctx, oracle_0_6b, fuse_qk):
     # the same four prompts as one 1379-row chunk with every projection forced through the prefill tile GEMM
     # (tile_gemm.hip; by default it takes over only when its 256-row tiles fill the chip, i.e. on ~4096-row chunks, which
     # the 8B batch-256 test below exercises): QKV, o_proj, gate/up + SiLU*mul and down_proj read planes in fragment order
-    # written by the norm, the attention and the SwiGLU epilogue.  Then 2 decode steps on the cache it filled.
+    # written by the norm, the attention and the SwiGLU epilogue.  fuse_qk: q/k-norm + RoPE + the K/V cache write run in
+    # the QKV GEMM's epilogue (one wave tile = one head) instead of the row kernel.  Then 2 decode steps on that cache.
     cfg, om = oracle_0_6b
     m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
     m.kv_alloc(num_blocks=12, max_seqs=4, max_batched_tokens=2048)
     m.set_option("tile_min_wgs", 1)
+    m.set_option("tile_fuse_qk", fuse_qk)
     rng = np.random.default_rng(21)
     seqs = [rng.integers(0, cfg.vocab_size, n).tolist() for n in (64, 292, 512, 511)]
     for step in range(3):
         ids, lg = m.step([0, 1, 2, 3], seqs, step == 0, want_logits=True)
         if step in (0, 2):
             rid, rlg = oracle_rows(om, seqs)
-            check_rows(f"0.6B x28 layers, tile GEMM prefill, contexts {[len(s) for s in seqs]}, step {step}", ids, lg, rid, rlg)
+            check_rows(f"0.6B x28 layers, tile GEMM prefill (fuse_qk={fuse_qk}), contexts {[len(s) for s in seqs]}, step {step}", ids, lg, rid, rlg)
         for s, t in zip(seqs, ids):
             s.append(int(t))
     m.close()
