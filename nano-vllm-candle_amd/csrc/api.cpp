@@ -1146,9 +1146,10 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
     const bool tile_on = !packed && tmin > 0 && R > kFusedMaxRows;
     const bool t_qkv = tile_on && gemm_tile_ok(R, NQ, H, 0, tmin) && (size_t)R * NQ <= m->slab_floats;
     const bool t_qkv_fused = t_qkv && m->opt_tile_fuse_qk && gemm_tile_qkv_ok(R, NQ, H, hd, tmin);
-    const bool t_o = tile_on && gemm_tile_ok(R, H, KO, 0, tmin) && (size_t)R * H <= m->slab_floats;
+    const int o_ks = tile_on ? gemm_tile_splits(R, H, KO, tmin, 4) : 0, d_ks = tile_on ? gemm_tile_splits(R, H, m->I_l, tmin, 4) : 0;
+    const bool t_o = o_ks > 0 && (size_t)o_ks * R * H <= m->slab_floats;
     const bool t_gu = tile_on && gemm_tile_ok(R, 2 * m->I_l, H, 2, tmin);
-    const bool t_down = t_gu && m->I_l % 32 == 0 && gemm_tile_ok(R, H, m->I_l, 0, tmin) && (size_t)R * H <= m->slab_floats;
+    const bool t_down = t_gu && m->I_l % 32 == 0 && d_ks > 0 && (size_t)d_ks * R * H <= m->slab_floats;
     for (int l = 0; l < m->L; ++l) {
         const LayerW& w = m->layers[l];
         NormArgs na;
@@ -1173,7 +1174,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
             // prompt chunk: q/k-norm + RoPE + KV write + q output in the QKV GEMM's epilogue (one wave tile = one head)
             PROF(m, PROF_GEMM, launch_gemm_tile_qkv(m->xh, m->xl, w.qkv, R, qa, tmin, s));
         } else {
-            if (t_qkv) { PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.qkv, R, 0, m->slabs, nullptr, nullptr, 0, tmin, s)); qa.n_slabs = 1; }
+            if (t_qkv) { PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.qkv, R, 0, m->slabs, nullptr, nullptr, 0, tmin, 1, nullptr, s)); qa.n_slabs = 1; }
             else rcg = gemm_slabs(m, m->xh, m->xl, H, w.qkv, m->slabs, R, 8, &qa.n_slabs, packed);
             if (rcg) return rcg;
             if (!fuse_qk) PROF(m, PROF_QK, launch_qk_norm_rope_kvwrite(qa, R, s));
@@ -1196,7 +1197,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         else PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
         // output projection (qwen3.rs:278) + TP all-reduce
         int o_slabs = 1;
-        if (t_o) PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.o, R, 0, m->slabs, nullptr, nullptr, 0, tmin, s));
+        if (t_o) PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.o, R, 0, m->slabs, nullptr, nullptr, 0, tmin, 4, &o_slabs, s));
         else rcg = gemm_slabs(m, m->xh, m->xl, KO, w.o, m->slabs, R, 8, &o_slabs, packed);
         if (rcg) return rcg;
         const float* oin; int ons;
@@ -1208,7 +1209,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         PROF(m, PROF_NORM, launch_add_rmsnorm(nb, R, s));
         // MLP (qwen3.rs:323-327)
         if (t_gu) {
-            PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.gu, R, 2, nullptr, m->xh2, m->xl2, t_down ? 1 : 0, tmin, s));
+            PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.gu, R, 2, nullptr, m->xh2, m->xl2, t_down ? 1 : 0, tmin, 1, nullptr, s));
         } else if (!packed && R <= kFusedMaxRows && gemm_rowpar_ok(2 * m->I_l, H, 1, R)) {
             // small gate/up: whole-K row-parallel kernel with the SiLU*mul epilogue
             RowParArgs rg;
@@ -1228,7 +1229,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
             PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, nullptr, s));
         }
         int d_slabs = 1;
-        if (t_down) PROF(m, PROF_GEMM, launch_gemm_tile(m->xh2, m->xl2, w.down, R, 0, m->slabs, nullptr, nullptr, 0, tmin, s));
+        if (t_down) PROF(m, PROF_GEMM, launch_gemm_tile(m->xh2, m->xl2, w.down, R, 0, m->slabs, nullptr, nullptr, 0, tmin, 4, &d_slabs, s));
         else rcg = gemm_slabs(m, m->xh2, m->xl2, m->I_l, w.down, m->slabs, R, 8, &d_slabs, packed);
         if (rcg) return rcg;
         rc = tp_reduce(m, R, d_slabs, &prev, &prev_ns);
@@ -1945,7 +1946,8 @@ extern "C" int nvllm_debug_gemm_tile_check(nvllm_ctx* ctx, int M, int N, int K, 
     HIPCHK(ctx, t.get(&w.data, (size_t)N * K / 8));
     HIPCHK(ctx, t.get(&xh, Mp * K)); HIPCHK(ctx, t.get(&xl, Mp * K)); HIPCHK(ctx, t.get(&ph, Mp * K)); HIPCHK(ctx, t.get(&pl, Mp * K));
     HIPCHK(ctx, t.get(&ah0, Mp * No)); HIPCHK(ctx, t.get(&al0, Mp * No)); HIPCHK(ctx, t.get(&ah1, Mp * No)); HIPCHK(ctx, t.get(&al1, Mp * No));
-    HIPCHK(ctx, t.get(&o0, (size_t)M * N)); HIPCHK(ctx, t.get(&o1, (size_t)M * N));
+    const int ks = mode == 0 ? std::max(1, gemm_tile_splits(M, N, K, 1, 4)) : 1;  // narrow outputs: the tile kernel splits K
+    HIPCHK(ctx, t.get(&o0, (size_t)M * N)); HIPCHK(ctx, t.get(&o1, (size_t)ks * M * N));
     HIPCHK(ctx, launch_synth_packed(w, 0, N, 4321, 0, 0, K, -1, s));
     HIPCHK(ctx, launch_synth_rowmajor_bf16(xh, 777, kSynthMatrix, 0, (int64_t)M * K, s));
     HIPCHK(ctx, launch_synth_rowmajor_bf16(xl, 778, kSynthMatrix, 0, (int64_t)M * K, s));
@@ -1954,7 +1956,8 @@ extern "C" int nvllm_debug_gemm_tile_check(nvllm_ctx* ctx, int M, int N, int K, 
     HIPCHK(ctx, hipMemsetAsync(ah1, 0, Mp * No * 2, s)); HIPCHK(ctx, hipMemsetAsync(al1, 0, Mp * No * 2, s));
     GemmPlan p = mode == 2 ? plan_gemm_swiglu(M, N, K) : plan_gemm(M, N, K, 1);
     auto old_go = [&]() { return mode == 2 ? launch_gemm_swiglu(p, xh, xl, K, w, M, ah0, al0, nullptr, s) : launch_gemm(p, xh, xl, K, w, o0, M, s); };
-    auto new_go = [&]() { return launch_gemm_tile(ph, pl, w, M, mode, o1, ah1, al1, act_packed, 1, s); };
+    int ns = 1;
+    auto new_go = [&]() { return launch_gemm_tile(ph, pl, w, M, mode, o1, ah1, al1, act_packed, 1, 4, mode == 0 ? &ns : nullptr, s); };
     float ms = 0;
     for (int i = 0; i < 2; ++i) HIPCHK(ctx, old_go());
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
@@ -1975,6 +1978,11 @@ extern "C" int nvllm_debug_gemm_tile_check(nvllm_ctx* ctx, int M, int N, int K, 
         std::vector<float> a((size_t)M * N), b((size_t)M * N);
         HIPCHK(ctx, hipMemcpy(a.data(), o0, a.size() * 4, hipMemcpyDeviceToHost));
         HIPCHK(ctx, hipMemcpy(b.data(), o1, b.size() * 4, hipMemcpyDeviceToHost));
+        for (int sl = 1; sl < ns; ++sl) {  // K splits: slabs are summed by the consumer
+            std::vector<float> c(a.size());
+            HIPCHK(ctx, hipMemcpy(c.data(), o1 + (size_t)sl * M * N, c.size() * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < c.size(); ++i) b[i] += c[i];
+        }
         for (size_t i = 0; i < a.size(); ++i) {
             const double d = std::fabs((double)a[i] - (double)b[i]);
             md = (d > md || d != d) ? d : md;

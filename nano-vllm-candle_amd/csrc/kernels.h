@@ -176,8 +176,11 @@ hipError_t launch_qk_norm_rope_kvwrite(const QkvArgs& a, int rows, hipStream_t s
 // xpack_off order).  min_wgs: smallest grid the kernel is used for (a 256-row tile needs many rows to fill 256 CUs).
 // hipErrorNotSupported = shape not covered.
 bool gemm_tile_ok(int M, int N, int K, int mode, int min_wgs);
+// mode 0 with n_slabs != nullptr may split K (narrow outputs, 128-row blocks): out = [*n_slabs][M][N], up to max_split slabs
+int gemm_tile_splits(int M, int N, int K, int min_wgs, int max_split);  // 0 = shape not covered
 hipError_t launch_gemm_tile(const bf16_bits* xh, const bf16_bits* xl, const PackedW& w, int M, int mode, float* out,
-                            bf16_bits* act_hi, bf16_bits* act_lo, int act_packed, int min_wgs, hipStream_t s);
+                            bf16_bits* act_hi, bf16_bits* act_lo, int act_packed, int min_wgs, int max_split, int* n_slabs,
+                            hipStream_t s);
 // mode 3 = the QKV projection of a prompt chunk with q/k-norm + RoPE + KV-cache write + q output in the epilogue
 // (qwen3.rs:205-234): needs 256-wide blocks and head_dim 128 (one wave tile = one head); qa.qkv is ignored.
 bool gemm_tile_qkv_ok(int M, int N, int K, int hd, int min_wgs);

@@ -39,22 +39,29 @@ struct TileArgs {
     uint16_t* act_lo = nullptr;
     int act_packed = 0;
     int M = 0, N = 0, KT = 0;
-    int MB = 0, NB = 0;         // 256-row blocks, 32*NTW-feature blocks
+    int kts = 0;                // k-tiles per K split (blockIdx.y); split y writes slab out + y*M*N (MODE 0 only)
+    int MB = 0, NB = 0;         // row blocks, feature blocks
     int map = 0;                // 0: id -> (nb fastest); 1: blocks of one XCD share rows; 2: share features
     QkvArgs q;                  // MODE 3
 };
 
-template <int NTW, int MODE>
+// WN = waves along the features (2: 256 rows x 32*NTW features; 4: 128 rows x 64*NTW features -- the narrow-output shape,
+// N = hidden size, where 256-row tiles cannot fill the chip)
+template <int NTW, int WN, int MODE>
 __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
-    constexpr int FR = 2 * NTW + 32;       // 1 KiB fragments per stage: 2*NTW of W, then [plane][16 row tiles] of x
+    constexpr int WM = 8 / WN;             // waves along the rows, 4 row tiles (64 rows) each
+    constexpr int XT = WM * 4;             // row tiles per workgroup
+    constexpr int FRW = WN * NTW;          // 1 KiB fragments per stage: W ...
+    constexpr int FR = FRW + 2 * XT;       // ... then [plane][row tile] of x
     constexpr int NI = (FR + 7) / 8;       // DMA wave-copies per wave per stage
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     uint4* lds = reinterpret_cast<uint4*>(smem_raw);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform: DMA sources / LDS targets stay scalar
     const int l15 = lane & 15, grp = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int KT = a.KT;
+    const int wm = wave / WN, wn = wave % WN;
+    const int KT = a.kts;                  // stages of this workgroup
+    const int kt0 = blockIdx.y * a.kts;
 
     // workgroup -> (row block, feature block); blockIdx % 8 labels the workgroups that land on one XCD
     int mb, nb;
@@ -73,11 +80,11 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int f = min(wave + 8 * i, FR - 1);
-        if (f < 2 * NTW) {
-            src[i] = a.wp + ((size_t)(nb * 2 * NTW + f) * KT) * 64;
+        if (f < FRW) {
+            src[i] = a.wp + ((size_t)(nb * FRW + f) * a.KT + kt0) * 64;
         } else {
-            const int g = f - 2 * NTW, plane = g >> 4, mt = min(mb * 16 + (g & 15), mtiles - 1);
-            src[i] = (plane ? a.xl : a.xh) + ((size_t)mt * KT) * 64;
+            const int g = f - FRW, plane = g / XT, mt = min(mb * XT + (g % XT), mtiles - 1);
+            src[i] = (plane ? a.xl : a.xh) + ((size_t)mt * a.KT + kt0) * 64;
         }
     }
     // k-tile s (clamped: the two issues past the end re-fetch the last k-tile into a stage nobody reads, so the
@@ -96,12 +103,12 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
     // this loop came out as lgkmcnt(0), i.e. each sub-step also waited for the reads it had just issued for the next one.
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem_raw;
     uint32_t w_cur = lds0 + (uint32_t)((wn * NTW) * 64 + lane) * 16;
-    uint32_t x_cur = lds0 + (uint32_t)((2 * NTW + wm * 4) * 64 + lane) * 16;
+    uint32_t x_cur = lds0 + (uint32_t)((FRW + wm * 4) * 64 + lane) * 16;
     uint32_t w_nxt = w_cur + FR * 1024, x_nxt = x_cur + FR * 1024, w_fre = w_cur + 2 * FR * 1024, x_fre = x_cur + 2 * FR * 1024;
     int fre = 2, cur_i = 0, nxt_i = 1;  // stage indices (scalar) for the DMA targets
 #define NVLLM_LDSR(DST_, ADDR_, OFF_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST_) : "v"(ADDR_), "n"(OFF_))
 #define NVLLM_WF(DST_, P_, J_) NVLLM_LDSR(DST_, P_, (J_) * 1024)
-#define NVLLM_XF(DST_, P_, PL_, MT_) NVLLM_LDSR(DST_, P_, ((PL_) * 16 + (MT_)) * 1024)
+#define NVLLM_XF(DST_, P_, PL_, MT_) NVLLM_LDSR(DST_, P_, ((PL_) * XT + (MT_)) * 1024)
 #define NVLLM_LGKM(N_) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N_) : "memory")
 
     f32x4 acc[NTW][4];
@@ -182,13 +189,14 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
 #undef NVLLM_LGKM
 
     // D[feature 4*grp + r][token l15]
-    const int nt0 = nb * 2 * NTW + wn * NTW;
+    const int nt0 = nb * FRW + wn * NTW;
+    const int row0 = mb * (WM * 64) + wm * 64;
     if constexpr (MODE == 0) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int row = mb * 256 + wm * 64 + b * 16 + l15;
+            const int row = row0 + b * 16 + l15;
             if (row < a.M) {
-                float* o = a.out + (size_t)row * a.N + (size_t)nt0 * 16 + grp * 4;
+                float* o = a.out + (size_t)blockIdx.y * a.M * a.N + (size_t)row * a.N + (size_t)nt0 * 16 + grp * 4;
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
                     const f32x4 v = acc[j][b];
@@ -197,13 +205,13 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
             }
         }
     } else if constexpr (MODE == 3) {
-        static_assert(MODE != 3 || NTW == 8, "one wave tile = one 128-wide head");
+        static_assert(MODE != 3 || (NTW == 8 && WN == 2), "one wave tile = one 128-wide head");
         const QkvArgs& q = a.q;
         const int hh = nb * 2 + wn;  // this wave's head: [q heads | k heads | v heads]
         const int nh = q.nh_l, kvl = q.kv.kv_l;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int row = mb * 256 + wm * 64 + b * 16 + l15;
+            const int row = row0 + b * 16 + l15;
             const int rowc = min(row, a.M - 1);
             const int pos = q.pos[rowc];
             const float ri = rownorm_rinv(q.rn, rowc);  // deferred input norm (1 when the planes were normalised)
@@ -268,7 +276,7 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
         const int I = a.N >> 1;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int row = mb * 256 + wm * 64 + b * 16 + l15;
+            const int row = row0 + b * 16 + l15;
             if (row < a.M) {
 #pragma unroll
                 for (int pr = 0; pr < NTW / 2; ++pr) {
@@ -289,56 +297,78 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
 }
 
 // ---- host side -------------------------------------------------------------------------------------
-// Features per wave (NTW) for an [M][N] output: the candidate (8 -> 256-wide, 6 -> 192-wide blocks) that needs the
-// fewest chip rounds x block width; 0 = shape not covered / too few workgroups to be worth it.
-static int tile_ntw(int M, int N, int K, int mode, int min_wgs) {
-    if (M < 1 || K % 64 != 0 || K < 128 || N % 32 != 0) return 0;
-    const int MB = (M + 255) / 256;
-    int best = 0;
-    int64_t best_cost = 0;
-    for (int ntw : {8, 6}) {
-        if (N % (32 * ntw) != 0) continue;
-        if (mode == 2 && ntw % 2) continue;
-        const int64_t wgs = (int64_t)MB * (N / (32 * ntw));
-        if (wgs < min_wgs) continue;
-        const int64_t cost = ((wgs + 255) / 256) * ntw;
-        if (!best || cost < best_cost) { best = ntw; best_cost = cost; }
+// Shape of the launch for an [M][N] output: block geometry (NTW, WN) and K splits.  Candidates: 256 x 256 and 256 x 192
+// (WN 2), and for outputs too narrow to fill the chip with 256-row blocks, 128 x 256 (WN 4, NTW 4) with up to 4 K
+// splits (f32 slabs, summed by the consumer like the chunked kernel's).  Cost = chip rounds x work of one block,
+// the narrow block charged 25 % more (more LDS reads per MFMA); ties go to fewer splits.  ntw == 0: not covered, or
+// fewer than min_wgs workgroups.
+struct TileShape { int ntw = 0, wn = 0, ks = 1; };
+static TileShape tile_shape(int M, int N, int K, int mode, int min_wgs, int max_split) {
+    TileShape best;
+    if (M < 1 || K % 64 != 0 || K < 128 || N % 32 != 0) return best;
+    const int KT = K / 32;
+    double best_cost = 0;
+    const int cand[3][2] = {{8, 2}, {6, 2}, {4, 4}};
+    for (const auto& c : cand) {
+        const int ntw = c[0], wn = c[1], cols = wn * ntw * 16, rows = (8 / wn) * 64;
+        if (N % cols != 0 || (mode == 2 && ntw % 2)) continue;
+        if (wn == 4 && mode != 0) continue;
+        const int64_t blocks = (int64_t)((M + rows - 1) / rows) * (N / cols);
+        for (int ks = 1; ks <= (wn == 4 && mode == 0 ? max_split : 1); ks *= 2) {
+            if (KT % (2 * ks) != 0 || (ks > 1 && KT / ks < 8)) continue;
+            const int64_t wgs = blocks * ks;
+            if (wgs < min_wgs) continue;
+            const double cost = (double)((wgs + 255) / 256) * rows * cols * (KT / ks) * (wn == 4 ? 1.25 : 1.0) * (1.0 + 0.02 * (ks - 1));
+            if (!best.ntw || cost < best_cost) { best.ntw = ntw; best.wn = wn; best.ks = ks; best_cost = cost; }
+        }
     }
     return best;
 }
 
-bool gemm_tile_ok(int M, int N, int K, int mode, int min_wgs) { return tile_ntw(M, N, K, mode, min_wgs) != 0; }
+bool gemm_tile_ok(int M, int N, int K, int mode, int min_wgs) { return tile_shape(M, N, K, mode, min_wgs, 1).ntw != 0; }
+int gemm_tile_splits(int M, int N, int K, int min_wgs, int max_split) { return tile_shape(M, N, K, 0, min_wgs, max_split).ntw ? tile_shape(M, N, K, 0, min_wgs, max_split).ks : 0; }
 
-template <int NTW, int MODE>
-static hipError_t tile_launch_t(TileArgs& a, hipStream_t s) {
-    a.NB = a.N / (32 * NTW);
-    a.MB = (a.M + 255) / 256;
+template <int NTW, int WN, int MODE>
+static hipError_t tile_launch_t(TileArgs& a, int ks, hipStream_t s) {
+    constexpr int rows = (8 / WN) * 64, FR = WN * NTW + 2 * (8 / WN) * 4;
+    a.NB = a.N / (WN * NTW * 16);
+    a.MB = (a.M + rows - 1) / rows;
+    a.kts = a.KT / ks;
     int grid;
     if (a.MB >= 8) { a.map = 1; grid = ((a.MB + 7) / 8) * 8 * a.NB; }
     else if (a.NB >= 8) { a.map = 2; grid = ((a.NB + 7) / 8) * 8 * a.MB; }
     else { a.map = 0; grid = a.MB * a.NB; }
-    const size_t lds = (size_t)3 * (2 * NTW + 32) * 1024;
+    const size_t lds = (size_t)3 * FR * 1024;
     static std::atomic<uint64_t> lds_set{0};
-    ensure_dyn_lds(reinterpret_cast<const void*>(gemm_tile_kernel<NTW, MODE>), lds, lds_set);
-    gemm_tile_kernel<NTW, MODE><<<grid, 512, lds, s>>>(a);
+    ensure_dyn_lds(reinterpret_cast<const void*>(gemm_tile_kernel<NTW, WN, MODE>), lds, lds_set);
+    gemm_tile_kernel<NTW, WN, MODE><<<dim3(grid, ks), 512, lds, s>>>(a);
     return hipGetLastError();
 }
 
+// n_slabs (nullable): K splits the launch wrote (out = [n_slabs][M][N]); nullptr -> never split
 hipError_t launch_gemm_tile(const bf16_bits* xh, const bf16_bits* xl, const PackedW& w, int M, int mode, float* out,
-                            bf16_bits* act_hi, bf16_bits* act_lo, int act_packed, int min_wgs, hipStream_t s) {
-    const int ntw = tile_ntw(M, w.N, w.K, mode, min_wgs);
-    if (!ntw) return hipErrorNotSupported;
+                            bf16_bits* act_hi, bf16_bits* act_lo, int act_packed, int min_wgs, int max_split, int* n_slabs,
+                            hipStream_t s) {
+    const TileShape t = tile_shape(M, w.N, w.K, mode, min_wgs, n_slabs ? max_split : 1);
+    if (!t.ntw) return hipErrorNotSupported;
     if (mode == 2 && act_packed && (w.N / 2) % 32 != 0) return hipErrorNotSupported;
     TileArgs a;
     a.xh = reinterpret_cast<const uint4*>(xh); a.xl = reinterpret_cast<const uint4*>(xl); a.wp = w.data;
     a.out = out; a.act_hi = act_hi; a.act_lo = act_lo; a.act_packed = act_packed;
     a.M = M; a.N = w.N; a.KT = w.K / 32;
-    if (mode == 0) return ntw == 8 ? tile_launch_t<8, 0>(a, s) : tile_launch_t<6, 0>(a, s);
-    if (mode == 2) return ntw == 8 ? tile_launch_t<8, 2>(a, s) : tile_launch_t<6, 2>(a, s);
+    if (n_slabs) *n_slabs = t.ks;
+    if (mode == 0) {
+        if (t.wn == 4) return tile_launch_t<4, 4, 0>(a, t.ks, s);
+        return t.ntw == 8 ? tile_launch_t<8, 2, 0>(a, 1, s) : tile_launch_t<6, 2, 0>(a, 1, s);
+    }
+    if (mode == 2) return t.ntw == 8 ? tile_launch_t<8, 2, 2>(a, 1, s) : tile_launch_t<6, 2, 2>(a, 1, s);
     return hipErrorInvalidValue;
 }
 
-bool gemm_tile_qkv_ok(int M, int N, int K, int hd, int min_wgs) { return hd == 128 && tile_ntw(M, N, K, 0, min_wgs) == 8; }
+bool gemm_tile_qkv_ok(int M, int N, int K, int hd, int min_wgs) {
+    const TileShape t = tile_shape(M, N, K, 0, min_wgs, 1);
+    return hd == 128 && t.ntw == 8 && t.wn == 2;
+}
 
 hipError_t launch_gemm_tile_qkv(const bf16_bits* xh, const bf16_bits* xl, const PackedW& w, int M, const QkvArgs& qa, int min_wgs,
                                 hipStream_t s) {
@@ -347,7 +377,7 @@ hipError_t launch_gemm_tile_qkv(const bf16_bits* xh, const bf16_bits* xl, const 
     TileArgs a;
     a.xh = reinterpret_cast<const uint4*>(xh); a.xl = reinterpret_cast<const uint4*>(xl); a.wp = w.data;
     a.M = M; a.N = w.N; a.KT = w.K / 32; a.q = qa;
-    return tile_launch_t<8, 3>(a, s);
+    return tile_launch_t<8, 2, 3>(a, 1, s);
 }
 
 // row-major plane [M][K] -> xpack_off order (tests and the tuning bench; the product's producers write the order directly)

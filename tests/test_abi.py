@@ -96,8 +96,9 @@ def test_hot_kernels_keep_their_register_budget():
         "_ZN5nvllm18gemm_rowdir_kernelILi6ELi16ELi2ELi1EEE": 4,   # gate/up    (N 6144, K 1024)
         "_ZN5nvllm18gemm_rowdir_kernelILi1ELi16ELi6ELi0EEE": 4,   # down_proj  (N 1024, K 3072)
         "_ZN5nvllm13lmhead_kernelILi4ELi5ELi4EEE": 2,             # LM head, 64 rows, vocabulary 151936, K 1024
-        "_ZN5nvllm16gemm_tile_kernelILi8ELi0EEE": 2,              # prefill tile GEMM: 8-wave workgroups, two waves per SIMD
-        "_ZN5nvllm16gemm_tile_kernelILi6ELi2EEE": 2,
+        "_ZN5nvllm16gemm_tile_kernelILi8ELi2ELi0EEE": 2,              # prefill tile GEMM: 8-wave workgroups, two waves per SIMD
+        "_ZN5nvllm16gemm_tile_kernelILi6ELi2ELi2EEE": 2,
+        "_ZN5nvllm16gemm_tile_kernelILi8ELi2ELi3EEE": 2,              # ... with the q/k-norm + RoPE + KV-write epilogue
     }
     for prefix, min_waves in want.items():
         hits = [(n, r) for n, r in res.items() if n.startswith(prefix)]

@@ -236,14 +236,15 @@ def test_device_generator_matches_oracle_generator(Ly, oracle):
     (4096, 4096, 1024, 0, 0),    # Qwen3-0.6B QKV on a full prompt chunk: one workgroup per CU
     (4090, 6144, 1024, 2, 0),    # gate/up + SiLU*mul, ragged last row tile, 192-wide blocks, row-major planes out
     (1000, 6144, 1024, 2, 1),    # few row blocks (feature-major XCD map), planes out in fragment order
-    (300, 1024, 3072, 0, 0),     # down_proj shape, two row blocks, plain workgroup map
+    (300, 1024, 3072, 0, 0),     # down_proj shape: narrow output -> 128-row blocks with K splits (slabs summed here)
+    (4096, 1024, 2048, 0, 0),    # o_proj on a full chunk: 128 x 256 blocks, 2 K splits
     (513, 512, 128, 0, 0),       # shortest K: four stages
 ])
 def test_prefill_tile_gemm_equals_the_chunked_kernel(Ly, M, N, K, mode, packed):
     # tile_gemm.hip (256-row workgroup tiles, both operands in fragment order, three-stage LDS ring) against the chunked
     # kernel (which test_linear_vs_oracle pins to the oracle) on the same synthetic operands.  Both accumulate k-tiles in
-    # ascending order, hi then lo, in f32, so the results are equal to the last bit; a published-too-early LDS stage or
-    # a wrong fragment shows as a large difference, not as rounding.
+    # ascending order, hi then lo, in f32, so unsplit results are equal to the last bit (K splits: to f32 rounding of the
+    # slab sum); a published-too-early LDS stage or a wrong fragment shows as a large difference, not as rounding.
     import ctypes as C
 
     from nano_vllm_candle_amd import _lib
@@ -253,4 +254,4 @@ def test_prefill_tile_gemm_equals_the_chunked_kernel(Ly, M, N, K, mode, packed):
     d, r, u0, u1 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
     _lib.check(_lib.lib().nvllm_debug_gemm_tile_check(ctx.h, M, N, K, mode, packed, 2, C.byref(d), C.byref(r), C.byref(u0), C.byref(u1)), ctx.h)
     assert r.value > 0
-    assert d.value <= 1e-6 * r.value, (d.value, r.value)
+    assert d.value <= 1e-5 * r.value, (d.value, r.value)
