@@ -1979,7 +1979,7 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
     constexpr int DC = HD / 32, DT = HD / 16, NWV = 4;
     constexpr int TILE_FRAGS = 2 * DC + DT;  // 1 KiB fragments of one 32-token K/V tile: K lo half, K hi half, V
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    uint4* lds = reinterpret_cast<uint4*>(smem_raw);  // [2 buffers][TILE_FRAGS][64]
+    uint4* lds = reinterpret_cast<uint4*>(smem_raw);  // [3 stages][TILE_FRAGS][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, grp = lane >> 4;
     const int kh = blockIdx.y;
@@ -2022,7 +2022,10 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (size_t)(buf * TILE_FRAGS + f) * 64), 16, 0, 0);
         }
     };
+    // ring of three stages: tile kt+2 is issued right after the barrier that opens tile kt, so a tile has two
+    // iterations to land (with one tile ahead the loop ran at the latency of a 16 KiB fetch per iteration)
     stage(0, 0);
+    if (wg_last >= 1) stage(1, 1);
     f16x8 qh[QT][DC], ql[QT][DC];
 #pragma unroll
     for (int t = 0; t < QT; ++t)
@@ -2050,10 +2053,14 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
 #pragma unroll
         for (int d = 0; d < DT; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int kt = 0; kt <= wg_last; ++kt) {
-        const int buf = kt & 1;
-        dma_publish_barrier();                      // tile kt has landed for every wave; the other buffer is free
-        if (kt + 1 <= wg_last) stage(kt + 1, buf ^ 1);
+    int buf = 0;
+    for (int kt = 0; kt <= wg_last; ++kt, buf = buf == 2 ? 0 : buf + 1) {
+        // every wave waits for its own copies of tile kt (all but the TILE_FRAGS / NWV newest: those are tile kt+1),
+        // then the barrier publishes them and says the stage read in iteration kt-1 is free.  Raw barrier: a
+        // __syncthreads() here drains vmcnt(0) and with it the tile that is meant to stay in flight.
+        if (kt + 1 <= wg_last) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TILE_FRAGS / NWV) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 2 <= wg_last) stage(kt + 2, buf == 0 ? 2 : buf - 1);
         if (kt > my_last) continue;                 // causal: this wave's rows end before this tile (it still stages)
         const int T0 = kt << 5;
         const int tokA = T0 + grp * 4, tokB = T0 + 16 + grp * 4;
@@ -2192,10 +2199,10 @@ hipError_t launch_attn_prefill(const AttnArgs& a, int n_tiles, hipStream_t s) {
     if (n_tiles % 4 || a.gqa < 1 || a.gqa > 16 || (a.kv.hd != 128 && a.kv.hd != 64)) return hipErrorInvalidValue;
     dim3 grid(n_tiles / 4, a.kv.kv_l);
     if (a.kv.hd == 128) {
-        const size_t lds = (size_t)2 * (2 * 4 + 8) * 1024;
+        const size_t lds = (size_t)3 * (2 * 4 + 8) * 1024;
         attn_prefill_kernel<128, 2><<<grid, 256, lds, s>>>(a);
     } else {
-        const size_t lds = (size_t)2 * (2 * 2 + 4) * 1024;
+        const size_t lds = (size_t)3 * (2 * 2 + 4) * 1024;
         attn_prefill_kernel<64, 2><<<grid, 256, lds, s>>>(a);
     }
     return hipGetLastError();
