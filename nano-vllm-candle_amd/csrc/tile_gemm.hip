@@ -82,7 +82,10 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
     for (int i = 0; i < NI; ++i) {
         const int f = min(wave + 8 * i, FR - 1);
         if (f < FRW) {
-            src[i] = a.wp + ((size_t)(nb * FRW + f) * a.KT + kt0) * 64;
+            // MODE 3: the block's two heads are nb and NB + nb, not neighbours: a V head (whose epilogue is scattered
+            // 2-byte cache stores) then always shares its workgroup with a q head, and the V tail spreads over twice the CUs
+            const int ntile = MODE == 3 ? (f < NTW ? nb : a.NB + nb) * NTW + f % NTW : nb * FRW + f;
+            src[i] = a.wp + ((size_t)ntile * a.KT + kt0) * 64;
         } else {
             const int g = f - FRW, plane = g / XT, mt = min(mb * XT + (g % XT), mtiles - 1);
             src[i] = (plane ? a.xl : a.xh) + ((size_t)mt * a.KT + kt0) * 64;
@@ -208,7 +211,7 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
     } else if constexpr (MODE == 3) {
         static_assert(MODE != 3 || (NTW == 8 && WN == 2), "one wave tile = one 128-wide head");
         const QkvArgs& q = a.q;
-        const int hh = nb * 2 + wn;  // this wave's head: [q heads | k heads | v heads]
+        const int hh = wn == 0 ? nb : a.NB + nb;  // this wave's head: [q heads | k heads | v heads]
         const int nh = q.nh_l, kvl = q.kv.kv_l;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
