@@ -326,7 +326,7 @@ struct nvllm_model {
     // step buffers
     uint32_t* d_ids = nullptr;
     int *d_pos = nullptr, *d_slot = nullptr, *d_tile_row0 = nullptr, *d_tile_nrows = nullptr, *d_tile_slot = nullptr,
-        *d_last_rows = nullptr, *d_tile_order = nullptr;
+        *d_last_rows = nullptr, *d_tile_order = nullptr, *d_tile_last = nullptr;
     float *resid = nullptr, *slabs = nullptr, *qbuf = nullptr, *logits = nullptr, *d_maxval = nullptr, *red = nullptr;
     bf16_bits *xh = nullptr, *xl = nullptr, *xh2 = nullptr, *xl2 = nullptr, *ctxh = nullptr, *ctxl = nullptr;
     float *ssqA = nullptr, *ssqB = nullptr;  // deferred-norm partial sums of squares [groups][kFusedMaxRows]
@@ -480,10 +480,10 @@ static void free_kv(nvllm_model* m) {
     for (auto p : m->vcache) (void)hipFree(p);
     m->kcache.clear(); m->vcache.clear();
     void* ptrs[] = {m->d_block_tables, m->d_ids, m->d_pos, m->d_slot, m->d_tile_row0, m->d_tile_nrows, m->d_tile_slot,
-                    m->d_last_rows, m->d_tile_order, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->xh2, m->xl2, m->ctxh, m->ctxl, m->ssqA, m->ssqB, m->d_next,
+                    m->d_last_rows, m->d_tile_order, m->d_tile_last, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->xh2, m->xl2, m->ctxh, m->ctxl, m->ssqA, m->ssqB, m->d_next,
                     m->part_val, m->part_idx, m->argmax_scratch, m->attn_po, m->attn_pml, m->tap_h, m->tap_res, m->cosv, m->sinv, m->tickets, m->qkv_out, m->d_keys, m->d_temps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    m->d_block_tables = nullptr; m->d_ids = nullptr; m->d_pos = m->d_slot = m->d_tile_row0 = m->d_tile_nrows = m->d_tile_slot = m->d_last_rows = m->d_tile_order = nullptr;
+    m->d_block_tables = nullptr; m->d_ids = nullptr; m->d_pos = m->d_slot = m->d_tile_row0 = m->d_tile_nrows = m->d_tile_slot = m->d_last_rows = m->d_tile_order = m->d_tile_last = nullptr;
     m->resid = m->slabs = m->qbuf = m->logits = m->d_maxval = m->red = nullptr; m->xh = m->xl = m->xh2 = m->xl2 = m->ctxh = m->ctxl = nullptr; m->ssqA = m->ssqB = nullptr; m->d_next = nullptr; m->part_val = nullptr; m->part_idx = nullptr; m->argmax_scratch = nullptr; m->attn_po = m->attn_pml = nullptr;
     m->tap_h = m->tap_res = nullptr; m->cosv = m->sinv = nullptr; m->tickets = nullptr; m->qkv_out = nullptr; m->d_keys = nullptr; m->d_temps = nullptr;
     if (m->h_stage) (void)hipHostFree(m->h_stage);
@@ -750,6 +750,7 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->d_tile_slot, 4 * R);
     if (!rc) rc = dmalloc(ctx, &m->d_last_rows, (size_t)max_seqs);
     if (!rc) rc = dmalloc(ctx, &m->d_tile_order, 4 * R);
+    if (!rc) rc = dmalloc(ctx, &m->d_tile_last, 4 * R);
     if (!rc) rc = dmalloc(ctx, &m->resid, R * m->H);
     if (!rc) rc = dmalloc(ctx, &m->slabs, m->slab_floats);
     if (!rc) rc = dmalloc(ctx, &m->qbuf, R * m->nh_l * m->hd);
@@ -786,7 +787,7 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->argmax_scratch, (size_t)max_seqs + 1);
     if (!rc) HIPCHK(ctx, hipMemsetAsync(m->argmax_scratch, 0, ((size_t)max_seqs + 1) * 8, ctx->stream));
     if (rc) return rc;
-    m->h_stage_bytes = (R * 19 + (size_t)max_seqs * 4) * sizeof(int) + 256;
+    m->h_stage_bytes = (R * 23 + (size_t)max_seqs * 4) * sizeof(int) + 256;
     HIPCHK(ctx, hipHostMalloc(&m->h_stage, m->h_stage_bytes, hipHostMallocDefault));
     // RoPE table: rotary_embedding.rs:56-80 (f32: inv_freq = 1/base^(2j/hd); angle = pos * inv_freq)
     m->rope_len = std::min(m->cfg.max_position_embeddings, m->max_blocks * kBlockTokens);
@@ -1036,6 +1037,7 @@ static int forward_chunk_fused(nvllm_model* m, const FusedPlan& fp, int R, int n
         AttnArgs aa;
         aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
         aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
+        aa.tile_last = m->d_tile_last;
         aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->ctxh; aa.out_lo = m->ctxl; aa.out_packed = packed;
         if (qt == 1) aa.tile_order = m->d_tile_order;
         if (fuse_qk) {
@@ -1182,6 +1184,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         AttnArgs aa;
         aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
         aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
+        aa.tile_last = m->d_tile_last;
         aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->xh; aa.out_lo = m->xl; aa.out_packed = packed || t_o;
         if (qt == 1) aa.tile_order = m->d_tile_order;
         if (fuse_qk) {
@@ -1373,6 +1376,8 @@ static int upload_chunk(nvllm_model* m, const RowPlan& p, int r0, int R, int t0,
         });
         for (int i = 0; i < T; ++i) h_ord[i] = ord[i];
     }
+    int* h_tl = h_ord + T;  // position of each tile's last row (-1: padding tile)
+    for (int i = 0; i < T; ++i) h_tl[i] = p.tile_nrows[t0 + i] > 0 ? p.pos[p.tile_row0[t0 + i] + p.tile_nrows[t0 + i] - 1] : -1;
     HIPCHK(ctx, hipMemcpyAsync(m->d_ids, h_ids, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(m->d_pos, h_pos, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(m->d_slot, h_slot, (size_t)R * 4, hipMemcpyHostToDevice, s));
@@ -1382,6 +1387,7 @@ static int upload_chunk(nvllm_model* m, const RowPlan& p, int r0, int R, int t0,
     if (!last_local.empty())
         HIPCHK(ctx, hipMemcpyAsync(m->d_last_rows, h_last, last_local.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(m->d_tile_order, h_ord, (size_t)T * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(m->d_tile_last, h_tl, (size_t)T * 4, hipMemcpyHostToDevice, s));
     return NVLLM_OK;
 }
 

@@ -197,6 +197,8 @@ struct AttnArgs {
     const int* tile_row0 = nullptr;    // per q-tile: first row, #rows, sequence slot
     const int* tile_nrows = nullptr;
     const int* tile_slot = nullptr;
+    const int* tile_last = nullptr;    // optional (prefill kernel): position of the tile's last row, -1 for an empty tile;
+                                       // saves the kernel a chain of dependent metadata loads per workgroup
     const int* pos = nullptr;          // [rows]
     // load balance (decode): tile_order[rank] = tile index, longest context first; the kernel walks it forwards
     // in even 256-workgroup rounds and backwards in odd ones so that co-resident workgroups (ids i and i+256

@@ -1980,12 +1980,15 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
     constexpr int TILE_FRAGS = 2 * DC + DT;  // 1 KiB fragments of one 32-token K/V tile: K lo half, K hi half, V
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     uint4* lds = reinterpret_cast<uint4*>(smem_raw);  // [3 stages][TILE_FRAGS][64]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, grp = lane >> 4;
     const int kh = blockIdx.y;
     const int tile = (int)blockIdx.x * NWV + wave;
-    const int slot = a.tile_slot[(int)blockIdx.x * NWV];  // all four tiles belong to one sequence
-    const int row0 = a.tile_row0[tile], nrows = a.tile_nrows[tile];
+    // wave-uniform values are made scalar explicitly (readfirstlane): the block-table lookup in stage() is then an s_load
+    // on the scalar counter; as a vector load it made every iteration wait vmcnt(0) -- for the lookup's own round trip
+    // AND for the K/V tiles meant to stay in flight
+    const int slot = __builtin_amdgcn_readfirstlane(a.tile_slot[(int)blockIdx.x * NWV]);  // all four tiles belong to one sequence
+    const int row0 = __builtin_amdgcn_readfirstlane(a.tile_row0[tile]), nrows = __builtin_amdgcn_readfirstlane(a.tile_nrows[tile]);
     const int gqa = a.gqa, tpq = 16 / gqa;
     const int kv_l = a.kv.kv_l;
     const int ldq = a.nh_l * HD;
@@ -1999,20 +2002,41 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
         my_pos[t] = valid ? a.pos[row0 + tok] : -1;
     }
     // tiles this wave needs: up to its last token; tiles the workgroup stages: up to the last token of its last real tile
-    const int my_last = nrows > 0 ? a.pos[row0 + nrows - 1] >> 5 : -1;
-    int wg_last = my_last;
+    int my_last, wg_last;
+    if (a.tile_last) {  // one 16-byte scalar load instead of twelve dependent ones
+        const int4 tl = *reinterpret_cast<const int4*>(a.tile_last + (size_t)blockIdx.x * NWV);
+        const int l0 = __builtin_amdgcn_readfirstlane(tl.x), l1 = __builtin_amdgcn_readfirstlane(tl.y),
+                  l2 = __builtin_amdgcn_readfirstlane(tl.z), l3 = __builtin_amdgcn_readfirstlane(tl.w);
+        const int mine = wave == 0 ? l0 : wave == 1 ? l1 : wave == 2 ? l2 : l3;
+        my_last = mine >= 0 ? mine >> 5 : -1;
+        const int mx = max(max(l0, l1), max(l2, l3));
+        wg_last = mx >= 0 ? mx >> 5 : -1;
+    } else {
+        my_last = nrows > 0 ? __builtin_amdgcn_readfirstlane(a.pos[row0 + nrows - 1]) >> 5 : -1;
+        wg_last = my_last;
 #pragma unroll
-    for (int w = 0; w < NWV; ++w) {
-        const int t2 = (int)blockIdx.x * NWV + w, n2 = a.tile_nrows[t2];
-        if (n2 > 0) wg_last = max(wg_last, a.pos[a.tile_row0[t2] + n2 - 1] >> 5);
+        for (int w = 0; w < NWV; ++w) {
+            const int t2 = (int)blockIdx.x * NWV + w, n2 = __builtin_amdgcn_readfirstlane(a.tile_nrows[t2]);
+            if (n2 > 0) wg_last = max(wg_last, __builtin_amdgcn_readfirstlane(a.pos[__builtin_amdgcn_readfirstlane(a.tile_row0[t2]) + n2 - 1]) >> 5);
+        }
     }
     if (wg_last < 0) return;  // four empty tiles (uniform)
     const int* bt = a.block_tables + (size_t)slot * a.max_blocks;
     const _Float16* kbase = reinterpret_cast<const _Float16*>(a.kv.k);
     const _Float16* vbase = reinterpret_cast<const _Float16*>(a.kv.v);
+    // Block id of tile kt_ by an explicit scalar load (hipcc turns the plain bt[] read into a vector load once the kernel
+    // has issued LDS-DMA writes -- no "noclobber" proof -- and then waits vmcnt(0) for it every iteration, draining the
+    // K/V tiles in flight).  Issued one iteration before its use; blk_ready() is the wait, tied to the value.
+    auto blk_load = [&](int kt_) {
+        int v;
+        const int* p = bt + (min(kt_, wg_last) >> 3);  // 8 tiles per 256-token block
+        asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(p));
+        return v;
+    };
+    auto blk_ready = [&](int& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v)::"memory"); };
     // stage tile kt into buffer buf: fragment f of the tile goes to wave f % 4 (TILE_FRAGS / 4 DMA loads each)
-    auto stage = [&](int kt, int buf) {
-        const int T0 = kt << 5, blk = bt[T0 >> 8], tb = T0 & 255;
+    auto stage = [&](int kt, int buf, int blk) {
+        const int T0 = kt << 5, tb = T0 & 255;
         const _Float16* kb = kbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 4) * (DC * 512) + lane * 8;
         const _Float16* vb = vbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 5) * (DT * 512) + lane * 8;
 #pragma unroll
@@ -2024,8 +2048,12 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
     };
     // ring of three stages: tile kt+2 is issued right after the barrier that opens tile kt, so a tile has two
     // iterations to land (with one tile ahead the loop ran at the latency of a 16 KiB fetch per iteration)
-    stage(0, 0);
-    if (wg_last >= 1) stage(1, 1);
+    int blk_a = blk_load(0), blk_b = blk_load(1);
+    blk_ready(blk_a);
+    blk_ready(blk_b);
+    stage(0, 0, blk_a);
+    if (wg_last >= 1) stage(1, 1, blk_b);
+    int blk_pf = blk_load(2);
     f16x8 qh[QT][DC], ql[QT][DC];
 #pragma unroll
     for (int t = 0; t < QT; ++t)
@@ -2060,7 +2088,9 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
         // __syncthreads() here drains vmcnt(0) and with it the tile that is meant to stay in flight.
         if (kt + 1 <= wg_last) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TILE_FRAGS / NWV) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 2 <= wg_last) stage(kt + 2, buf == 0 ? 2 : buf - 1);
+        blk_ready(blk_pf);
+        if (kt + 2 <= wg_last) stage(kt + 2, buf == 0 ? 2 : buf - 1, blk_pf);
+        blk_pf = blk_load(kt + 3);
         if (kt > my_last) continue;                 // causal: this wave's rows end before this tile (it still stages)
         const int T0 = kt << 5;
         const int tokA = T0 + grp * 4, tokB = T0 + 16 + grp * 4;
