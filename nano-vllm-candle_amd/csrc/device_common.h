@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -24,6 +25,14 @@ __device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) 
     lo = __builtin_bit_cast(uint16_t, (__bf16)(x - (float)h));
 }
 __device__ __forceinline__ _Float16 f16_sat(float x) { return (_Float16)fminf(fmaxf(x, -65504.f), 65504.f); }
+
+// max of three without the canonicalising v_max_f32 x, x that fmaxf() adds per operand (operands here are MFMA results
+// and finite constants: no signalling NaN to quiet)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -2002,6 +2002,7 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
         my_pos[t] = valid ? a.pos[row0 + tok] : -1;
     }
     // tiles this wave needs: up to its last token; tiles the workgroup stages: up to the last token of its last real tile
+    const int first_pos = nrows > 0 ? __builtin_amdgcn_readfirstlane(a.pos[row0]) : 0;  // every row of this wave is at or after it
     int my_last, wg_last;
     if (a.tile_last) {  // one 16-byte scalar load instead of twelve dependent ones
         const int4 tl = *reinterpret_cast<const int4*>(a.tile_last + (size_t)blockIdx.x * NWV);
@@ -2111,41 +2112,64 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
                 sb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, ql[t][c], sb[t], 0, 0, 0);
             }
         }
+        // Online softmax, written for the VALU: this block, not the MFMAs, set the kernel's time (30 of 45 us per launch
+        // as first written).  Raw v_exp_f32 (arguments are <= 0, a flushed denormal is 0 either way; exp2f() costs a
+        // compare, a select and an ldexp on top), v_max3 without the NaN canonicalisation fmaxf() pays per operand,
+        // the causal mask only on tiles that reach past the wave's first row, and no rescale of O when no row's
+        // maximum moved.
         f16x8 P[QT];
         float alpha[QT];
+        auto softmax = [&](auto masked_c) {
+            constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            float mt = -1e30f;
+            for (int t = 0; t < QT; ++t) {
+                float va[4], vb[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (tokA + r <= my_pos[t]) mt = fmaxf(mt, sa[t][r]);
-                if (tokB + r <= my_pos[t]) mt = fmaxf(mt, sb[t][r]);
+                for (int r = 0; r < 4; ++r) {
+                    va[r] = (!MASKED || tokA + r <= my_pos[t]) ? sa[t][r] : -1e30f;
+                    vb[r] = (!MASKED || tokB + r <= my_pos[t]) ? sb[t][r] : -1e30f;
+                }
+                float mt = max3_raw(va[0], va[1], va[2]);
+                mt = max3_raw(mt, va[3], vb[0]);
+                mt = max3_raw(mt, vb[1], vb[2]);
+                mt = max3_raw(mt, vb[3], m[t]);                       // the running maximum is the same in the row's four lanes
+                mt = max3_raw(mt, __shfl_xor(mt, 16), mt);
+                const float mn = max3_raw(mt, __shfl_xor(mt, 32), mt);
+                alpha[t] = __builtin_amdgcn_exp2f(m[t] - mn);
+                m[t] = mn;
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pa = __builtin_amdgcn_exp2f(va[r] - mn), pb = __builtin_amdgcn_exp2f(vb[r] - mn);
+                    if (MASKED) {  // exp2(-1e30 - mn) is 0 already unless mn itself is the -1e30 of a row with no valid token yet
+                        pa = (tokA + r <= my_pos[t]) ? pa : 0.f;
+                        pb = (tokB + r <= my_pos[t]) ? pb : 0.f;
+                    }
+                    ps += pa + pb;
+                    P[t][r] = (_Float16)pa;
+                    P[t][4 + r] = (_Float16)pb;
+                }
+                lsum[t] = lsum[t] * alpha[t] + ps;
             }
-            mt = fmaxf(mt, __shfl_xor(mt, 16));
-            mt = fmaxf(mt, __shfl_xor(mt, 32));
-            const float mn = fmaxf(m[t], mt);
-            alpha[t] = exp2f(m[t] - mn);
-            m[t] = mn;
-            float ps = 0.f;
+        };
+        if (T0 + 31 <= first_pos) softmax(std::false_type{});
+        else softmax(std::true_type{});
+        bool moved = false;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pa = (tokA + r <= my_pos[t]) ? exp2f(sa[t][r] - mn) : 0.f;
-                const float pb = (tokB + r <= my_pos[t]) ? exp2f(sb[t][r] - mn) : 0.f;
-                ps += pa + pb;
-                P[t][r] = (_Float16)pa;
-                P[t][4 + r] = (_Float16)pb;
-            }
-            lsum[t] = lsum[t] * alpha[t] + ps;
+        for (int t = 0; t < QT; ++t) moved = moved || alpha[t] != 1.0f;
+        if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    o[t][d][0] *= alpha[t]; o[t][d][1] *= alpha[t]; o[t][d][2] *= alpha[t]; o[t][d][3] *= alpha[t];
+                }
         }
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
             const f16x8 fv = __builtin_bit_cast(f16x8, lds[(size_t)(buf * TILE_FRAGS + 2 * DC + d) * 64 + lane]);
 #pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                f32x4 acc = o[t][d];
-                acc[0] *= alpha[t]; acc[1] *= alpha[t]; acc[2] *= alpha[t]; acc[3] *= alpha[t];
-                o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fv, P[t], acc, 0, 0, 0);
-            }
+            for (int t = 0; t < QT; ++t) o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fv, P[t], o[t][d], 0, 0, 0);
         }
     }
     // every wave owns its rows for the whole context: normalise and store (D[dim 4*grp+reg][q row l15] -> out[row][head dims])
