@@ -399,7 +399,8 @@ def main():
     # `traffic` (PMC HBM bytes of THIS run) needs rocprofv3 around the process, so it is null in the live line; the
     # committed counter pass of the same command is quoted beside it with its own algorithmic bytes (a different run,
     # hence a different context: never mixed into `achieved`)
-    for pmc_path in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_fetch_size.json")), reverse=True):
+    default_workload = a.model == "qwen3-0.6b" and a.batch == 64 and a.prompt_min == 64 and a.prompt_max == 512 and a.seed == 0
+    for pmc_path in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_fetch_size.json") and default_workload), reverse=True):
         pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_path))).get(dom_name)
         if pmc:
             roof["traffic_from_profile"] = {"file": "profiles/" + pmc_path, "fetch_bytes_per_launch": pmc["fetch_bytes_per_launch"],
