@@ -43,7 +43,6 @@ struct TileArgs {
     int MB = 0, NB = 0;         // row blocks, feature blocks
     int map = 0;                // 0: id -> (nb fastest); 1: blocks of one XCD share rows; 2: share features
     QkvArgs q;                  // MODE 3
-    int dbg = 0;
 };
 
 // WN = waves along the features (2: 256 rows x 32*NTW features; 4: 128 rows x 64*NTW features -- the narrow-output shape,
@@ -237,8 +236,8 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
                 for (int j = 0; j < 4; ++j) {
                     const int d = j * 16 + grp * 4;
                     const float4 w1 = *reinterpret_cast<const float4*>(w + d), w2 = *reinterpret_cast<const float4*>(w + 64 + d);
-                    const float4 cs = *reinterpret_cast<const float4*>(q.cos + (size_t)((a.dbg & 2) ? 0 : pos) * 64 + d);
-                    const float4 sn = *reinterpret_cast<const float4*>(q.sin + (size_t)((a.dbg & 2) ? 0 : pos) * 64 + d);
+                    const float4 cs = *reinterpret_cast<const float4*>(q.cos + (size_t)pos * 64 + d);
+                    const float4 sn = *reinterpret_cast<const float4*>(q.sin + (size_t)pos * 64 + d);
                     const float w1a[4] = {w1.x, w1.y, w1.z, w1.w}, w2a[4] = {w2.x, w2.y, w2.z, w2.w};
                     const float ca[4] = {cs.x, cs.y, cs.z, cs.w}, sa[4] = {sn.x, sn.y, sn.z, sn.w};
 #pragma unroll
@@ -250,7 +249,6 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
                 }
                 if (row < a.M) {
                     if (hh < nh) {
-                        if (a.dbg & 4) continue;
                         float* qo = q.q_out + (size_t)row * (nh * 128) + (size_t)hh * 128 + grp * 4;
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
@@ -267,7 +265,7 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
                         }
                     }
                 }
-            } else if (row < a.M && !(a.dbg & 1)) {  // V head: plain copy into the PV fragment order (tokens are the fast index there)
+            } else if (row < a.M) {  // V head: plain copy into the PV fragment order (tokens are the fast index there)
                 const int blk = q.block_tables[(size_t)q.slot[row] * q.max_blocks + (pos >> 8)];
                 _Float16* v = reinterpret_cast<_Float16*>(q.kv.v) + (size_t)(blk * kvl + (hh - nh - kvl)) * kBlockTokens * 128;
 #pragma unroll
@@ -382,7 +380,6 @@ hipError_t launch_gemm_tile_qkv(const bf16_bits* xh, const bf16_bits* xl, const 
     TileArgs a;
     a.xh = reinterpret_cast<const uint4*>(xh); a.xl = reinterpret_cast<const uint4*>(xl); a.wp = w.data;
     a.M = M; a.N = w.N; a.KT = w.K / 32; a.q = qa;
-    a.dbg = getenv("NVLLM_TILE_DBG") ? atoi(getenv("NVLLM_TILE_DBG")) : 0;
     return tile_launch_t<8, 2, 3>(a, 1, s);
 }
 
