@@ -1146,9 +1146,13 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
     const int KO = m->nh_l * hd;
     const int tmin = m->opt_tile_min_wgs;
     const bool tile_on = !packed && tmin > 0 && R > kFusedMaxRows;
-    const bool t_qkv = tile_on && gemm_tile_ok(R, NQ, H, 0, tmin) && (size_t)R * NQ <= m->slab_floats;
+    // K splits (f32 slabs summed by the consumer): up to 4 on prompt chunks; a few hundred decode rows are MFMA-bound
+    // too (hi + lo planes: 4 flops per weight byte and row) and need up to 8 to fill the chip
+    const int max_ks = R <= 512 ? 8 : 4;
+    const int o_ks = tile_on ? gemm_tile_splits(R, H, KO, tmin, max_ks) : 0, d_ks = tile_on ? gemm_tile_splits(R, H, m->I_l, tmin, max_ks) : 0;
+    const int q_ks = tile_on ? gemm_tile_splits(R, NQ, H, tmin, max_ks) : 0;
+    const bool t_qkv = q_ks > 0 && (size_t)q_ks * R * NQ <= m->slab_floats;
     const bool t_qkv_fused = t_qkv && m->opt_tile_fuse_qk && gemm_tile_qkv_ok(R, NQ, H, hd, tmin);
-    const int o_ks = tile_on ? gemm_tile_splits(R, H, KO, tmin, 4) : 0, d_ks = tile_on ? gemm_tile_splits(R, H, m->I_l, tmin, 4) : 0;
     const bool t_o = o_ks > 0 && (size_t)o_ks * R * H <= m->slab_floats;
     const bool t_gu = tile_on && gemm_tile_ok(R, 2 * m->I_l, H, 2, tmin);
     const bool t_down = t_gu && m->I_l % 32 == 0 && d_ks > 0 && (size_t)d_ks * R * H <= m->slab_floats;
@@ -1176,7 +1180,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
             // prompt chunk: q/k-norm + RoPE + KV write + q output in the QKV GEMM's epilogue (one wave tile = one head)
             PROF(m, PROF_GEMM, launch_gemm_tile_qkv(m->xh, m->xl, w.qkv, R, qa, tmin, s));
         } else {
-            if (t_qkv) { PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.qkv, R, 0, m->slabs, nullptr, nullptr, 0, tmin, 1, nullptr, s)); qa.n_slabs = 1; }
+            if (t_qkv) PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.qkv, R, 0, m->slabs, nullptr, nullptr, 0, tmin, max_ks, &qa.n_slabs, s));
             else rcg = gemm_slabs(m, m->xh, m->xl, H, w.qkv, m->slabs, R, 8, &qa.n_slabs, packed);
             if (rcg) return rcg;
             if (!fuse_qk) PROF(m, PROF_QK, launch_qk_norm_rope_kvwrite(qa, R, s));
@@ -1200,7 +1204,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         else PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
         // output projection (qwen3.rs:278) + TP all-reduce
         int o_slabs = 1;
-        if (t_o) PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.o, R, 0, m->slabs, nullptr, nullptr, 0, tmin, 4, &o_slabs, s));
+        if (t_o) PROF(m, PROF_GEMM, launch_gemm_tile(m->xh, m->xl, w.o, R, 0, m->slabs, nullptr, nullptr, 0, tmin, max_ks, &o_slabs, s));
         else rcg = gemm_slabs(m, m->xh, m->xl, KO, w.o, m->slabs, R, 8, &o_slabs, packed);
         if (rcg) return rcg;
         const float* oin; int ons;
@@ -1232,7 +1236,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
             PROF(m, PROF_GEMM, launch_gemm_swiglu(pg, m->xh, m->xl, H, w.gu, R, m->xh2, m->xl2, nullptr, s));
         }
         int d_slabs = 1;
-        if (t_down) PROF(m, PROF_GEMM, launch_gemm_tile(m->xh2, m->xl2, w.down, R, 0, m->slabs, nullptr, nullptr, 0, tmin, 4, &d_slabs, s));
+        if (t_down) PROF(m, PROF_GEMM, launch_gemm_tile(m->xh2, m->xl2, w.down, R, 0, m->slabs, nullptr, nullptr, 0, tmin, max_ks, &d_slabs, s));
         else rcg = gemm_slabs(m, m->xh2, m->xl2, m->I_l, w.down, m->slabs, R, 8, &d_slabs, packed);
         if (rcg) return rcg;
         rc = tp_reduce(m, R, d_slabs, &prev, &prev_ns);

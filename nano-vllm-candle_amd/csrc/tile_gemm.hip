@@ -301,10 +301,11 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
 
 // ---- host side -------------------------------------------------------------------------------------
 // Shape of the launch for an [M][N] output: block geometry (NTW, WN) and K splits.  Candidates: 256 x 256 and 256 x 192
-// (WN 2), and for outputs too narrow to fill the chip with 256-row blocks, 128 x 256 (WN 4, NTW 4) with up to 4 K
-// splits (f32 slabs, summed by the consumer like the chunked kernel's).  Cost = chip rounds x work of one block,
-// the narrow block charged 25 % more (more LDS reads per MFMA); ties go to fewer splits.  ntw == 0: not covered, or
-// fewer than min_wgs workgroups.
+// (WN 2) and 128 x 256 (WN 4, NTW 4) for outputs too narrow or too short to fill the chip with 256-row blocks; mode 0
+// may split K (f32 slabs, summed by the consumer like the chunked kernel's).  Cost in microseconds = chip rounds x one
+// block's MFMA time (hi + lo planes, half the dense peak as the sustained rate, the narrow block charged 25 % more for
+// its LDS reads per MFMA) + the slabs' write and re-read when K is split.  ntw == 0: not covered, or fewer than
+// min_wgs workgroups.
 struct TileShape { int ntw = 0, wn = 0, ks = 1; };
 static TileShape tile_shape(int M, int N, int K, int mode, int min_wgs, int max_split) {
     TileShape best;
@@ -315,13 +316,14 @@ static TileShape tile_shape(int M, int N, int K, int mode, int min_wgs, int max_
     for (const auto& c : cand) {
         const int ntw = c[0], wn = c[1], cols = wn * ntw * 16, rows = (8 / wn) * 64;
         if (N % cols != 0 || (mode == 2 && ntw % 2)) continue;
-        if (wn == 4 && mode != 0) continue;
         const int64_t blocks = (int64_t)((M + rows - 1) / rows) * (N / cols);
-        for (int ks = 1; ks <= (wn == 4 && mode == 0 ? max_split : 1); ks *= 2) {
+        for (int ks = 1; ks <= (mode == 0 ? max_split : 1); ks *= 2) {
             if (KT % (2 * ks) != 0 || (ks > 1 && KT / ks < 8)) continue;
             const int64_t wgs = blocks * ks;
             if (wgs < min_wgs) continue;
-            const double cost = (double)((wgs + 255) / 256) * rows * cols * (KT / ks) * (wn == 4 ? 1.25 : 1.0) * (1.0 + 0.02 * (ks - 1));
+            const double block_us = 4.0 * rows * cols * (double)(K / ks) / (2.5e15 * 0.5 / 256) * 1e6 * (wn == 4 ? 1.25 : 1.0);
+            const double slab_us = ks > 1 ? 2.0 * ks * (double)M * N * 4 / 4e12 * 1e6 : 0.0;
+            const double cost = (double)((wgs + 255) / 256) * block_us + slab_us;
             if (!best.ntw || cost < best_cost) { best.ntw = ntw; best.wn = wn; best.ks = ks; best_cost = cost; }
         }
     }
@@ -362,9 +364,12 @@ hipError_t launch_gemm_tile(const bf16_bits* xh, const bf16_bits* xl, const Pack
     if (n_slabs) *n_slabs = t.ks;
     if (mode == 0) {
         if (t.wn == 4) return tile_launch_t<4, 4, 0>(a, t.ks, s);
-        return t.ntw == 8 ? tile_launch_t<8, 2, 0>(a, 1, s) : tile_launch_t<6, 2, 0>(a, 1, s);
+        return t.ntw == 8 ? tile_launch_t<8, 2, 0>(a, t.ks, s) : tile_launch_t<6, 2, 0>(a, t.ks, s);
     }
-    if (mode == 2) return t.ntw == 8 ? tile_launch_t<8, 2, 2>(a, 1, s) : tile_launch_t<6, 2, 2>(a, 1, s);
+    if (mode == 2) {
+        if (t.wn == 4) return tile_launch_t<4, 4, 2>(a, 1, s);
+        return t.ntw == 8 ? tile_launch_t<8, 2, 2>(a, 1, s) : tile_launch_t<6, 2, 2>(a, 1, s);
+    }
     return hipErrorInvalidValue;
 }
 

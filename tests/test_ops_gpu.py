@@ -239,6 +239,8 @@ def test_device_generator_matches_oracle_generator(Ly, oracle):
     (300, 1024, 3072, 0, 0),     # down_proj shape: narrow output -> 128-row blocks with K splits (slabs summed here)
     (4096, 1024, 2048, 0, 0),    # o_proj on a full chunk: 128 x 256 blocks, 2 K splits
     (513, 512, 128, 0, 0),       # shortest K: four stages
+    (256, 6144, 4096, 0, 0),     # a few hundred decode rows (Qwen3-8B QKV at batch 256): one row block, K splits fill the chip
+    (256, 6144, 1024, 2, 1),     # ... and the SwiGLU epilogue on 128-row blocks
 ])
 def test_prefill_tile_gemm_equals_the_chunked_kernel(Ly, M, N, K, mode, packed):
     # tile_gemm.hip (256-row workgroup tiles, both operands in fragment order, three-stage LDS ring) against the chunked
