@@ -382,8 +382,11 @@ def test_full_size_batch64_properties(pkg, ctx):
     for i in (0, 37):
         _, l1 = m2.step([0], [prompts[i]], True, want_logits=True)
         # not bit-equal: a different batch shape picks a different split-K / chunking (f32 sum order), and an f16
-        # rounding flip in a cached K/V element moves logits by ~1e-4; the bound is half the parity tolerance
-        assert rel_err(l1[0], lg[i]) < 5e-4
+        # rounding flip in a cached K/V element moves logits by ~1e-4; the bound is half the parity tolerance and must
+        # not drift: the measured value is printed (round 1: 9.0e-5)
+        e = rel_err(l1[0], lg[i])
+        print(f"[parity] sequence {i} alone vs inside the batch of 64: {e:.3e} (bound 5e-4)")
+        assert e < 5e-4
     # decode continues deterministically: two identical runs agree bit for bit
     a = [m.decode_next()[:64].copy() for _ in range(3)]
     m.step(list(range(64)), prompts, True)

@@ -166,7 +166,12 @@ def test_gqa_interleaved_expand(Ly):
     assert ctx[:, :3].tolist() == [[1, 2, 3], [1, 2, 3], [4, 5, 6], [4, 5, 6]]  # kv heads [h0,h0,h1,h1]
 
 
-# f16 K/V storage + f16 P bound the error; 2e-3 on raw attention outputs of N(0,1) data
+# Op-level bound, NOT the model tolerance: raw attention outputs of N(0,1) q/k/v (scores of sigma ~ sqrt(hd) before the
+# scale, far hotter than a trained model's) with f16 K/V storage and f16 P.  The model-level tests hold
+# the north-star 1e-3 on logits; this one pins the kernel's arithmetic, and prints what it measured.
+ATTN_OP_TOL = 2e-3
+
+
 @pytest.mark.parametrize("B,nh,kv,T,hd", [(1, 2, 1, 1, 64), (1, 2, 1, 5, 64), (2, 4, 2, 37, 128), (1, 16, 8, 300, 128),
                                           (2, 8, 2, 70, 64), (1, 8, 1, 33, 128), (1, 5, 1, 40, 128), (1, 16, 16, 31, 128),
                                           (1, 2, 2, 600, 128)])
@@ -175,7 +180,9 @@ def test_attention_vs_oracle(Ly, oracle, rng, B, nh, kv, T, hd):
     k = rng.standard_normal((B, kv, T, hd)).astype(np.float32)
     v = rng.standard_normal((B, kv, T, hd)).astype(np.float32)
     got = Ly.Attention(nh, hd, hd ** -0.5)(q, k, v)
-    assert rel_err(got, oracle.attention(q, k, v)) < 2e-3
+    err = rel_err(got, oracle.attention(q, k, v))
+    print(f"[parity] attention op B={B} nh={nh} kv={kv} T={T} hd={hd}: {err:.3e} (op bound {ATTN_OP_TOL:g})")
+    assert err < ATTN_OP_TOL
 
 
 def test_attention_online_softmax_rescale_branch(Ly, oracle, rng):
@@ -186,7 +193,7 @@ def test_attention_online_softmax_rescale_branch(Ly, oracle, rng):
     v = rng.standard_normal((B, kv, T, hd)).astype(np.float32)
     k[0, 0, 150] = 6.0 * q[0, 0, 199] / np.linalg.norm(q[0, 0, 199]) * 3
     got = Ly.Attention(nh, hd, hd ** -0.5)(q, k, v)
-    assert rel_err(got, oracle.attention(q, k, v)) < 2e-3
+    assert rel_err(got, oracle.attention(q, k, v)) < ATTN_OP_TOL
 
 
 def test_causal_rows_ignore_later_tokens(Ly, rng):
