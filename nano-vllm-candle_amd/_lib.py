@@ -90,6 +90,7 @@ _SIGS = {
     "nvllm_op_synth_bf16": (C.c_int, [_vp, C.c_char_p, C.c_uint64, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_uint16)]),
     "nvllm_debug_gemm_bench": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "nvllm_debug_gemm_bench2": (C.c_int, [_vp] + [C.c_int] * 10 + [C.POINTER(C.c_float)]),
+    "nvllm_debug_get_counter": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "nvllm_debug_gemm_tile_check": (C.c_int, [_vp] + [C.c_int] * 6 + [C.POINTER(C.c_float)] * 4),
     "nvllm_debug_xcc_map": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "nvllm_debug_attn_bench": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_float)]),
@@ -100,7 +101,7 @@ _SIGS = {
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 _DEBUG_EXPORTS_ADDED_LATER = ("nvllm_debug_stamps", "nvllm_debug_stamps_read", "nvllm_ctx_create_null_comm", "nvllm_debug_set_option",
-                              "nvllm_debug_gemm_tile_check")
+                              "nvllm_debug_gemm_tile_check", "nvllm_debug_get_counter")
 
 _lib = None
 

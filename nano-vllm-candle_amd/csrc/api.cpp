@@ -40,6 +40,8 @@ struct LoopGroup {
     uint64_t generation = 0;
     std::vector<float> acc;
     std::vector<unsigned char> gather;
+    std::vector<float*> os_data;      // one-shot all-reduce buffers of the ranks (same process, same device: plain pointers)
+    std::vector<uint32_t*> os_flag;
 };
 static std::mutex g_groups_mu;
 static std::map<std::string, std::shared_ptr<LoopGroup>> g_groups;
@@ -53,6 +55,16 @@ struct nvllm_ctx {
     int tp_rank = 0, tp_size = 1;
     ncclComm_t comm = nullptr;
     std::string err;
+    // one-shot all-reduce (oneshot.hip), opt-in; empty when not set up
+    bool oneshot = false;
+    float* os_data = nullptr;     // [2 generations][tp][os_slot] f32, uncached device memory
+    uint32_t* os_flag = nullptr;  // [2][tp]
+    unsigned* os_done = nullptr;  // push kernel's workgroup counter
+    int* os_err = nullptr;        // set by a wait that timed out
+    size_t os_slot = 0;
+    uint64_t os_calls = 0;
+    OneShotPeers os_peers;
+    std::vector<void*> os_ipc;    // peer mappings opened with hipIpcOpenMemHandle
 };
 
 static thread_local std::string g_create_err;
@@ -143,6 +155,114 @@ static int comm_allgather(nvllm_ctx* ctx, const void* send, void* recv, size_t b
     return NVLLM_OK;
 }
 
+// group barrier of the loopback communicator (host threads)
+static void loop_barrier(LoopGroup& g) {
+    std::unique_lock<std::mutex> lk(g.mu);
+    const uint64_t gen = g.generation;
+    if (++g.arrived == g.size) { g.arrived = 0; ++g.generation; g.cv.notify_all(); }
+    else g.cv.wait(lk, [&] { return g.generation != gen; });
+}
+
+// Loopback test double only: its ranks are host threads of ONE process whose streams share a handful of hardware
+// queues, so a wait kernel enqueued before a peer's push could sit IN FRONT of that push in the same queue and spin
+// until its timeout.  A host barrier between "every rank has enqueued its push" and "anybody enqueues a wait" removes
+// that order; the data / flag protocol on the device is unchanged.  RCCL ranks (one process, one GPU each) skip it.
+static void oneshot_loopback_order(nvllm_ctx* ctx) {
+    if (ctx->loop) loop_barrier(*ctx->loop);
+}
+
+static void oneshot_free(nvllm_ctx* ctx) {
+    for (void* p : ctx->os_ipc) (void)hipIpcCloseMemHandle(p);
+    ctx->os_ipc.clear();
+    if (ctx->os_data) (void)hipFree(ctx->os_data);
+    if (ctx->os_flag) (void)hipFree(ctx->os_flag);
+    if (ctx->os_done) (void)hipFree(ctx->os_done);
+    if (ctx->os_err) (void)hipFree(ctx->os_err);
+    ctx->os_data = nullptr; ctx->os_flag = nullptr; ctx->os_done = nullptr; ctx->os_err = nullptr;
+    ctx->oneshot = false; ctx->os_slot = 0; ctx->os_peers = OneShotPeers();
+}
+
+// Buffers + peer mappings of the one-shot all-reduce.  Collective: every rank of the group calls it with the same
+// slot size.  RCCL ranks exchange HIP IPC handles through ncclAllGather; loopback ranks exchange pointers through the
+// group.  Any failure leaves the context on the RCCL / loopback all-reduce (oneshot == false) and is reported in err.
+static int oneshot_setup(nvllm_ctx* ctx, size_t slot_floats) {
+    if (ctx->tp_size < 2 || ctx->tp_size > 8 || ctx->null_comm) return NVLLM_OK;
+    if (ctx->oneshot && ctx->os_slot >= slot_floats) return NVLLM_OK;
+    oneshot_free(ctx);
+    const int tp = ctx->tp_size;
+    slot_floats = (slot_floats + 3) / 4 * 4;
+    const size_t data_bytes = (size_t)2 * tp * slot_floats * 4, flag_bytes = (size_t)2 * tp * 4;
+    auto alloc = [&](void** p, size_t bytes) {  // uncached: peers' writes must be what this GPU reads next, not an L2 line
+        hipError_t e = hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained); }
+        return e;
+    };
+    bool ok = alloc((void**)&ctx->os_data, data_bytes) == hipSuccess && alloc((void**)&ctx->os_flag, std::max<size_t>(flag_bytes, 256)) == hipSuccess &&
+              hipMalloc((void**)&ctx->os_done, 256) == hipSuccess && hipMalloc((void**)&ctx->os_err, 256) == hipSuccess;
+    if (ok) ok = hipMemset(ctx->os_flag, 0, std::max<size_t>(flag_bytes, 256)) == hipSuccess && hipMemset(ctx->os_done, 0, 256) == hipSuccess &&
+                 hipMemset(ctx->os_err, 0, 256) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    int all_ok = ok ? 1 : 0;
+    if (ctx->loop) {
+        LoopGroup& g = *ctx->loop;
+        {
+            std::lock_guard<std::mutex> lk(g.mu);
+            g.os_data.resize(tp, nullptr); g.os_flag.resize(tp, nullptr);
+            g.os_data[ctx->tp_rank] = ok ? ctx->os_data : nullptr;
+            g.os_flag[ctx->tp_rank] = ok ? ctx->os_flag : nullptr;
+        }
+        loop_barrier(g);
+        {
+            std::lock_guard<std::mutex> lk(g.mu);
+            for (int r = 0; r < tp; ++r) {
+                ctx->os_peers.data[r] = g.os_data[r]; ctx->os_peers.flag[r] = g.os_flag[r];
+                if (!g.os_data[r] || !g.os_flag[r]) all_ok = 0;
+            }
+        }
+        loop_barrier(g);  // nobody re-registers before everybody has read
+    } else {
+        // [tp][2] IPC handles through the communicator that exists anyway
+        struct Rec { hipIpcMemHandle_t data, flag; int ok; int pad[3]; };
+        Rec mine; memset(&mine, 0, sizeof mine);
+        mine.ok = ok && hipIpcGetMemHandle(&mine.data, ctx->os_data) == hipSuccess && hipIpcGetMemHandle(&mine.flag, ctx->os_flag) == hipSuccess;
+        Rec* d_all = nullptr;
+        std::vector<Rec> all(tp);
+        if (hipMalloc((void**)&d_all, sizeof(Rec) * tp) != hipSuccess) { oneshot_free(ctx); return fail(ctx, NVLLM_EHIP, "one-shot all-reduce: staging allocation failed"); }
+        (void)hipMemcpy(d_all + ctx->tp_rank, &mine, sizeof mine, hipMemcpyHostToDevice);
+        ncclResult_t r = ncclAllGather(d_all + ctx->tp_rank, d_all, sizeof(Rec), ncclUint8, ctx->comm, ctx->stream);
+        if (r == ncclSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess &&
+            hipMemcpy(all.data(), d_all, sizeof(Rec) * tp, hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int q = 0; q < tp; ++q) all_ok = all_ok && all[q].ok;
+            for (int q = 0; q < tp && all_ok; ++q) {
+                if (q == ctx->tp_rank) { ctx->os_peers.data[q] = ctx->os_data; ctx->os_peers.flag[q] = ctx->os_flag; continue; }
+                void *pd = nullptr, *pf = nullptr;
+                if (hipIpcOpenMemHandle(&pd, all[q].data, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { all_ok = 0; break; }
+                ctx->os_ipc.push_back(pd);
+                if (hipIpcOpenMemHandle(&pf, all[q].flag, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { all_ok = 0; break; }
+                ctx->os_ipc.push_back(pf);
+                ctx->os_peers.data[q] = (float*)pd; ctx->os_peers.flag[q] = (uint32_t*)pf;
+            }
+        } else {
+            all_ok = 0;
+        }
+        // every rank must take the same decision: a rank on the one-shot path would wait for flags nobody raises
+        int* d_ok = reinterpret_cast<int*>(d_all);  // reuse the staging buffer (freed below)
+        int h_ok = all_ok;
+        (void)hipMemcpy(d_ok, &h_ok, 4, hipMemcpyHostToDevice);
+        if (ncclAllReduce(d_ok, d_ok, 1, ncclInt, ncclMin, ctx->comm, ctx->stream) != ncclSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+            hipMemcpy(&h_ok, d_ok, 4, hipMemcpyDeviceToHost) != hipSuccess) h_ok = 0;
+        all_ok = h_ok;
+        (void)hipFree(d_all);
+    }
+    if (!all_ok) {
+        oneshot_free(ctx);
+        return fail(ctx, NVLLM_OK, "one-shot all-reduce not available on this group (allocation or IPC mapping failed): using the communicator's all-reduce");
+    }
+    ctx->os_slot = slot_floats;
+    ctx->os_calls = 0;
+    ctx->oneshot = true;
+    return NVLLM_OK;
+}
+
 extern "C" const char* nvllm_last_error(const nvllm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 extern "C" int nvllm_rccl_unique_id(void* out_id) {
@@ -225,6 +345,7 @@ extern "C" int nvllm_ctx_destroy(nvllm_ctx* c) {
     if (!c) return NVLLM_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    oneshot_free(c);
     if (c->comm) ncclCommDestroy(c->comm);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
@@ -336,6 +457,7 @@ struct nvllm_model {
     // consumer launch on MI355X (Qwen3-8B batch 64: 8.6 vs 6.4 ms/step; 32B TP=8 shard: 8.9 vs 6.5 ms) -- one workgroup
     // per n-group reads every slab behind an agent-scope release of all the others.  nvllm_debug_set_option turns it on.
     int opt_stream_combine = 0;
+    int opt_oneshot_allreduce = getenv("NVLLM_ONESHOT_AR") ? atoi(getenv("NVLLM_ONESHOT_AR")) : 0;  // TP decode: one-shot all-reduce (set before kv_alloc)
     int opt_tile_fuse_qk = 1;    // QKV tile GEMM with the q/k-norm + RoPE + KV-write epilogue (head_dim 128, 256-wide blocks)
     int opt_tile_min_wgs = 192;  // prefill tile GEMM: smallest grid it is used for (256-row tiles need rows to fill 256 CUs)
     unsigned* tickets = nullptr;             // arrival counters of the streaming GEMM's in-launch combine (zero between launches)
@@ -718,6 +840,10 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     m->max_seqs = max_seqs;
     // every row-sized buffer holds max_rows rows; a decode step has one row per sequence, so max_seqs rows must fit
     m->max_rows = std::max({max_batched_tokens, max_seqs, 16});
+    if (m->opt_oneshot_allreduce && ctx->tp_size > 1 && !ctx->null_comm) {
+        // collective: every rank of the group reaches this with the same option (slot = the largest fused decode message)
+        (void)oneshot_setup(ctx, (size_t)kFusedMaxRows * m->H);
+    }
     const int by_pos = (m->cfg.max_position_embeddings + kBlockTokens - 1) / kBlockTokens;
     m->max_blocks = std::max(1, std::min(num_blocks, by_pos));
     const size_t per_layer = (size_t)num_blocks * m->kv_l * kBlockTokens * m->hd;
@@ -862,13 +988,27 @@ extern "C" int nvllm_debug_layer_tap(nvllm_model* m, int layer, int what, float*
 // Sum split-K slabs into m->red and all-reduce across the TP group; returns the buffer the next
 // norm should read (with n_slabs = 1).  Row-parallel outputs only (o_proj, down_proj): the
 // all-reduce the reference's RowParallelLinear lacks (src/layers/linear.rs:184-198).
-static int tp_reduce(nvllm_model* m, int rows, int ns, const float** in, int* n_slabs) {
+// *stride: floats between the slabs the consumer has to sum
+static int tp_reduce(nvllm_model* m, int rows, int ns, const float** in, int* n_slabs, int64_t* stride) {
     nvllm_ctx* ctx = m->ctx;
+    *stride = (int64_t)rows * m->H;
     if (ctx->tp_size == 1) { *in = m->slabs; *n_slabs = ns; return NVLLM_OK; }
     float* buf = m->slabs;  // a single complete partial is reduced where it lies
     if (ns > 1) {
         HIPCHK(ctx, launch_slab_sum(m->slabs, ns, (int64_t)rows * m->H, nullptr, rows, m->H, m->red, ctx->stream));
         buf = m->red;
+    }
+    if (ctx->oneshot && (size_t)rows * m->H <= ctx->os_slot && ((size_t)rows * m->H) % 4 == 0) {
+        // one-shot all-reduce (oneshot.hip): the consumer sums the tp slots like split-K slabs
+        const int gen = (int)(ctx->os_calls & 1);
+        const uint32_t seq = (uint32_t)(++ctx->os_calls);
+        HIPCHK(ctx, launch_oneshot_push(buf, (size_t)rows * m->H, ctx->os_peers, ctx->tp_size, ctx->tp_rank, ctx->os_slot, gen, seq, ctx->os_done, ctx->stream));
+        oneshot_loopback_order(ctx);
+        HIPCHK(ctx, launch_oneshot_wait(ctx->os_flag, ctx->tp_size, gen, seq, ctx->os_err, ctx->stream));
+        *in = ctx->os_data + (size_t)gen * ctx->tp_size * ctx->os_slot;
+        *n_slabs = ctx->tp_size;
+        *stride = (int64_t)ctx->os_slot;
+        return NVLLM_OK;
     }
     int rc_ = comm_allreduce_sum(ctx, buf, (size_t)rows * m->H);
     if (rc_) return rc_;
@@ -955,9 +1095,9 @@ static int forward_chunk_fused(nvllm_model* m, const FusedPlan& fp, int R, int n
         return sa;
     };
     // prep: resid (+)= in; x' = w (.) resid as hi/lo; ssq[row] (one group).  in == nullptr: layer-0 embedding rows
-    auto prep = [&](const float* in, const float* w, int out_packed) -> int {
+    auto prep = [&](const float* in, const float* w, int out_packed, int in_slabs = 1, int64_t in_stride = 0) -> int {
         NormArgs na;
-        if (in) { na.in = in; na.n_slabs = 1; na.residual_in = m->resid; }
+        if (in) { na.in = in; na.n_slabs = in_slabs; na.slab_stride = in_stride; na.residual_in = m->resid; }
         else { na.ids = m->d_ids; na.embed = m->embed; }
         na.weight = w; na.eps = eps; na.H = H; na.xh = m->xh; na.xl = m->xl; na.residual_out = m->resid; na.ssq_out = m->ssqB;
         na.out_packed = out_packed;
@@ -998,6 +1138,16 @@ static int forward_chunk_fused(nvllm_model* m, const FusedPlan& fp, int R, int n
             GemmPlan pg = plan_gemm(R, H, K, 8);
             PROF(m, PROF_GEMM, launch_gemm(pg, xh_, xl_, K, w, m->slabs, R, s));
             HIPCHK(ctx, launch_slab_sum(m->slabs, pg.n_split, (int64_t)R * H, nullptr, R, H, m->red, s));
+        }
+        if (ctx->oneshot && (size_t)R * H <= ctx->os_slot && (R * H) % 4 == 0) {
+            // one-shot all-reduce: push the partial into every peer's slot, wait for the tp flags, and let the norm prep
+            // sum the tp slots like split-K slabs (every rank adds them in rank order: identical bits on all ranks)
+            const int gen = (int)(ctx->os_calls & 1);
+            const uint32_t seq = (uint32_t)(++ctx->os_calls);
+            HIPCHK(ctx, launch_oneshot_push(m->red, (size_t)R * H, ctx->os_peers, ctx->tp_size, ctx->tp_rank, ctx->os_slot, gen, seq, ctx->os_done, s));
+            oneshot_loopback_order(ctx);
+            HIPCHK(ctx, launch_oneshot_wait(ctx->os_flag, ctx->tp_size, gen, seq, ctx->os_err, s));
+            return prep(ctx->os_data + (size_t)gen * ctx->tp_size * ctx->os_slot, next_w, o_packed, ctx->tp_size, (int64_t)ctx->os_slot);
         }
         int rc = comm_allreduce_sum(ctx, m->red, (size_t)R * H);
         if (rc) return rc;
@@ -1135,6 +1285,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
     const int NQ = (m->nh_l + 2 * m->kv_l) * hd;
     const float* prev = nullptr;  // output of the previous layer's MLP (slabs or reduced)
     int prev_ns = 1;
+    int64_t prev_stride = 0;
     m->tap_rows = R;
     // big-model decode: when all four projections of a layer run the streaming GEMM, the activation planes between
     // the row kernels and the GEMMs stay in MFMA fragment order (xpack_off): x staging costs 3x per byte otherwise
@@ -1163,7 +1314,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         if (l == 0) {  // residual None: normed = norm(x), residual = x  (qwen3.rs:382-386)
             na.ids = m->d_ids; na.embed = m->embed;
         } else {       // qwen3.rs:378
-            na.in = prev; na.n_slabs = prev_ns; na.slab_stride = (int64_t)R * H; na.residual_in = m->resid;
+            na.in = prev; na.n_slabs = prev_ns; na.slab_stride = prev_stride; na.residual_in = m->resid;
         }
         PROF(m, PROF_NORM, launch_add_rmsnorm(na, R, s));
         // QKV projection (qwen3.rs:205)
@@ -1208,10 +1359,11 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         else rcg = gemm_slabs(m, m->xh, m->xl, KO, w.o, m->slabs, R, 8, &o_slabs, packed);
         if (rcg) return rcg;
         const float* oin; int ons;
-        int rc = tp_reduce(m, R, o_slabs, &oin, &ons);
+        int64_t ostride = 0;
+        int rc = tp_reduce(m, R, o_slabs, &oin, &ons, &ostride);
         if (rc) return rc;
         NormArgs nb;  // post-attention add + norm (qwen3.rs:393)
-        nb.in = oin; nb.n_slabs = ons; nb.slab_stride = (int64_t)R * H; nb.residual_in = m->resid; nb.residual_out = m->resid;
+        nb.in = oin; nb.n_slabs = ons; nb.slab_stride = ostride; nb.residual_in = m->resid; nb.residual_out = m->resid;
         nb.weight = w.ln2; nb.eps = eps; nb.H = H; nb.xh = m->xh; nb.xl = m->xl; nb.out_packed = packed || t_gu;
         PROF(m, PROF_NORM, launch_add_rmsnorm(nb, R, s));
         // MLP (qwen3.rs:323-327)
@@ -1239,10 +1391,10 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         if (t_down) PROF(m, PROF_GEMM, launch_gemm_tile(m->xh2, m->xl2, w.down, R, 0, m->slabs, nullptr, nullptr, 0, tmin, max_ks, &d_slabs, s));
         else rcg = gemm_slabs(m, m->xh2, m->xl2, m->I_l, w.down, m->slabs, R, 8, &d_slabs, packed);
         if (rcg) return rcg;
-        rc = tp_reduce(m, R, d_slabs, &prev, &prev_ns);
+        rc = tp_reduce(m, R, d_slabs, &prev, &prev_ns, &prev_stride);
         if (rc) return rc;
         if (m->taps) {
-            HIPCHK(ctx, launch_slab_sum(prev, prev_ns, (int64_t)R * H, nullptr, R, H, m->tap_h + (size_t)l * m->max_rows * H, s));
+            HIPCHK(ctx, launch_slab_sum(prev, prev_ns, prev_stride, nullptr, R, H, m->tap_h + (size_t)l * m->max_rows * H, s));
             HIPCHK(ctx, hipMemcpyAsync(m->tap_res + (size_t)l * m->max_rows * H, m->resid, (size_t)R * H * 4, hipMemcpyDeviceToDevice, s));
         }
     }
@@ -1250,7 +1402,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         // final add + norm on the rows that are a sequence's last token only (qwen3.rs:497), then LM head
         // on those rows (qwen3.rs:542-550 computes all rows; only row len-1 is used, llm_engine.rs:181-183)
         NormArgs nf;
-        nf.in = prev; nf.n_slabs = prev_ns; nf.slab_stride = (int64_t)R * H; nf.residual_in = m->resid; nf.row_idx = m->d_last_rows;
+        nf.in = prev; nf.n_slabs = prev_ns; nf.slab_stride = prev_stride; nf.residual_in = m->resid; nf.row_idx = m->d_last_rows;
         nf.weight = m->norm; nf.eps = eps; nf.H = H; nf.xh = m->xh; nf.xl = m->xl;
         HIPCHK(ctx, launch_add_rmsnorm(nf, n_last, s));
         GemmPlan pl = plan_lmhead(n_last, m->V_l, H);
@@ -1300,10 +1452,24 @@ static void set_attn_split(nvllm_model* m, int n_seqs, int max_len) {
 }
 
 // greedy ids (and optionally logits) of `n` last rows to the host; handles the vocab-parallel case
+// a one-shot all-reduce whose wait timed out (a peer never raised its flag) has left wrong sums: report it
+static int oneshot_check(nvllm_ctx* ctx) {
+    if (!ctx->oneshot) return NVLLM_OK;
+    int e = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&e, ctx->os_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (e) {
+        (void)hipMemsetAsync(ctx->os_err, 0, 4, ctx->stream);
+        return fail(ctx, NVLLM_ERCCL, "one-shot all-reduce: a peer's flag never arrived (timed out); this step's results are invalid");
+    }
+    return NVLLM_OK;
+}
+
 static int finish_logits(nvllm_model* m, int n, uint32_t* next_ids, float* last_logits) {
     nvllm_ctx* ctx = m->ctx;
     hipStream_t s = ctx->stream;
     const int tp = ctx->tp_size, V = m->cfg.vocab_size, Vl = m->V_l;
+    { const int rc_os = oneshot_check(ctx); if (rc_os) return rc_os; }
     if (tp == 1) {
         if (next_ids) HIPCHK(ctx, hipMemcpyAsync(next_ids, m->d_next, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         if (last_logits) HIPCHK(ctx, hipMemcpyAsync(last_logits, m->logits, (size_t)n * V * 4, hipMemcpyDeviceToHost, s));
@@ -1643,9 +1809,17 @@ extern "C" int64_t nvllm_last_step_bytes(const nvllm_model* m) { return m ? m->l
 extern "C" int nvllm_debug_set_option(nvllm_model* m, const char* name, int value) {
     if (!m || !name) return NVLLM_EINVAL;
     if (!strcmp(name, "stream_combine")) { m->opt_stream_combine = value; return NVLLM_OK; }
+    if (!strcmp(name, "oneshot_allreduce")) { m->opt_oneshot_allreduce = value; return NVLLM_OK; }  // takes effect at the next kv_alloc
     if (!strcmp(name, "tile_fuse_qk")) { m->opt_tile_fuse_qk = value; return NVLLM_OK; }
     if (!strcmp(name, "tile_min_wgs")) { m->opt_tile_min_wgs = value; return NVLLM_OK; }  // <= 0: never use the tile GEMM
     return fail(m->ctx, NVLLM_EINVAL, "unknown option '%s'", name);
+}
+
+// counters for tests: "oneshot_calls" = all-reduces this model's context has run on the one-shot device path
+extern "C" int nvllm_debug_get_counter(nvllm_model* m, const char* name, int64_t* value) {
+    if (!m || !name || !value) return NVLLM_EINVAL;
+    if (!strcmp(name, "oneshot_calls")) { *value = (int64_t)m->ctx->os_calls; return NVLLM_OK; }
+    return fail(m->ctx, NVLLM_EINVAL, "unknown counter '%s'", name);
 }
 
 extern "C" int nvllm_debug_stamps(nvllm_model* m, int enable) {

@@ -188,6 +188,17 @@ hipError_t launch_gemm_tile_qkv(const bf16_bits* xh, const bf16_bits* xl, const 
                                 hipStream_t s);
 hipError_t launch_xpack_plane(const bf16_bits* src, bf16_bits* dst, int M, int K, hipStream_t s);
 
+// ---- one-shot all-reduce for TP decode (oneshot.hip) -----------------------------------------------------------
+// every rank's buffer: data [2 generations][tp][slot_floats] f32, flag [2][tp] u32; data[q] / flag[q] = rank q's buffers
+// as mapped into THIS process
+struct OneShotPeers {
+    float* data[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t* flag[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+hipError_t launch_oneshot_push(const float* src, size_t n, const OneShotPeers& p, int tp, int rank, size_t slot_floats, int gen,
+                               uint32_t seq, unsigned* done, hipStream_t s);
+hipError_t launch_oneshot_wait(const uint32_t* flags, int tp, int gen, uint32_t seq, int* err, hipStream_t s);
+
 // ---- paged attention (prefill tiles and decode rows alike) ----------------------------------------
 struct AttnArgs {
     const float* q = nullptr;          // [rows][nh_l*hd], already scaled by q_scale

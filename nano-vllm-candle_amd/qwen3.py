@@ -289,6 +289,12 @@ class Qwen3ForCausalLM:
         """tuning switch of the model (include/nvllm_amd_debug.h nvllm_debug_set_option)"""
         _lib.check(_lib.lib().nvllm_debug_set_option(self.h, name.encode(), int(value)), self.ctx.h)
 
+    def counter(self, name):
+        """debug counter of the model (include/nvllm_amd_debug.h nvllm_debug_get_counter)"""
+        v = C.c_int64()
+        _lib.check(_lib.lib().nvllm_debug_get_counter(self.h, name.encode(), C.byref(v)), self.ctx.h)
+        return int(v.value)
+
     def enable_taps(self, on=True):
         _lib.check(_lib.lib().nvllm_debug_enable_taps(self.h, int(on)), self.ctx.h)
 

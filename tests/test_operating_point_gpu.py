@@ -181,12 +181,14 @@ def test_32b_layer_shapes_tp1_vs_oracle(pkg, ctx, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("n_seqs,combine", [(4, 0), (20, 0), (20, 1)])
-def test_32b_layer_shapes_tp8_shards_vs_oracle(pkg, oracle, n_seqs, combine):
+@pytest.mark.parametrize("n_seqs,combine,oneshot", [(4, 0, 0), (20, 0, 0), (20, 1, 0), (4, 0, 1), (20, 0, 1)])
+def test_32b_layer_shapes_tp8_shards_vs_oracle(pkg, oracle, n_seqs, combine, oneshot):
     # the per-rank shapes of Qwen3-32B at TP=8 (8 q heads / 1 kv head per rank, I/8 = 3200 columns, V/8 vocab rows)
     # on ONE GPU through the in-process loopback communicator (one host thread per rank): sharded load, per-rank
     # kernels, the two all-reduces per layer, vocab-parallel ids.  RCCL itself is not exercised (unpinned until
-    # a multi-GPU run exists).
+    # a multi-GPU run exists).  oneshot: the decode all-reduces run on the DEVICE (oneshot.hip: every rank writes its
+    # partial into a slot of every peer's buffer, flags, the norm prep sums the slots) with the peers' buffers shared as
+    # plain pointers -- the single-GPU test double of the IPC-mapped xGMI form.
     cfg = pkg.Qwen3Config.tiny(vocab_size=2048, hidden_size=5120, head_dim=128, num_hidden_layers=1,
                                num_attention_heads=64, num_key_value_heads=8, intermediate_size=25600)
     om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(0)
@@ -198,9 +200,12 @@ def test_32b_layer_shapes_tp8_shards_vs_oracle(pkg, oracle, n_seqs, combine):
 
     def worker(rank):
         try:
-            c = pkg.Context(0, tp_rank=rank, tp_size=tp, loopback_group=f"g32b_{n_seqs}_{combine}")
+            c = pkg.Context(0, tp_rank=rank, tp_size=tp, loopback_group=f"g32b_{n_seqs}_{combine}_{oneshot}")
             mm = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=0, ctx=c)
+            mm.set_option("oneshot_allreduce", oneshot)  # takes effect in kv_alloc (a collective: buffers are exchanged)
             mm.kv_alloc(n_seqs + 4, n_seqs, 1024)
+            if oneshot:
+                assert b"not available" not in pkg._lib.lib().nvllm_last_error(c.h), pkg._lib.lib().nvllm_last_error(c.h)
             mm.set_option("stream_combine", combine)  # 1: streaming GEMMs with the in-launch combine (7 launches per layer)
             my = [list(s) for s in seqs]
             out = []
@@ -209,6 +214,9 @@ def test_32b_layer_shapes_tp8_shards_vs_oracle(pkg, oracle, n_seqs, combine):
                 out.append((ids.copy(), lg.copy()))
                 for s, t in zip(my, ids):
                     s.append(int(t))
+            # two all-reduces per layer went through the device path in every step whose message fits a slot (<= 128 rows)
+            os_steps = (steps - 1) + (1 if sum(len(s) for s in seqs) <= 128 else 0)
+            assert mm.counter("oneshot_calls") == (2 * cfg.num_hidden_layers * os_steps if oneshot else 0)
             results[rank] = out
             mm.close()
             c.close()
