@@ -305,7 +305,7 @@ gemm_kernel(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, in
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float g = acc[2 * pr][b][r] * ri, u = acc[2 * pr + 1][b][r] * ri;
-                        split_bf16((g / (1.0f + __expf(-g))) * u, h[r], l[r]);
+                        split_bf16(silu_mul(g, u), h[r], l[r]);
                     }
                     *reinterpret_cast<uint2*>(act_hi + (size_t)row * I + f0) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
                     *reinterpret_cast<uint2*>(act_lo + (size_t)row * I + f0) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
@@ -943,7 +943,7 @@ __global__ void __launch_bounds__(NWN * NWK * 64) gemm_rowpar_kernel(RowParArgs 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float g = acc[b][r] * ri, u = up[r] * ri;
-                    split_bf16((g / (1.0f + __expf(-g))) * u, h[r], l[r]);
+                    split_bf16(silu_mul(g, u), h[r], l[r]);
                 }
                 const size_t o = (size_t)row * I + (size_t)pair * 16 + grp * 4;
                 *reinterpret_cast<uint2*>(a.oh + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
@@ -1100,7 +1100,7 @@ __global__ void __launch_bounds__(NWK * 64) gemm_rowdir_kernel(RowParArgs a, con
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float g = sum[r] * ri, u = up[r] * ri;
-                split_bf16((g / (1.0f + __expf(-g))) * u, h[r], l[r]);
+                split_bf16(silu_mul(g, u), h[r], l[r]);
             }
             const size_t o = a.o_packed ? xpack_off(row, pair * 16 + grp * 4, I >> 5) : (size_t)row * I + (size_t)pair * 16 + grp * 4;
             *reinterpret_cast<uint2*>(a.oh + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
@@ -2306,8 +2306,8 @@ __global__ void __launch_bounds__(256) silu_mul_kernel(const float* __restrict__
             g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
             u.x += u2.x; u.y += u2.y; u.z += u2.z; u.w += u2.w;
         }
-        const float y0 = (g.x / (1.0f + __expf(-g.x))) * u.x, y1 = (g.y / (1.0f + __expf(-g.y))) * u.y;
-        const float y2 = (g.z / (1.0f + __expf(-g.z))) * u.z, y3 = (g.w / (1.0f + __expf(-g.w))) * u.w;
+        const float y0 = silu_mul(g.x, u.x), y1 = silu_mul(g.y, u.y);
+        const float y2 = silu_mul(g.z, u.z), y3 = silu_mul(g.w, u.w);
         if (y) *reinterpret_cast<float4*>(y + (size_t)r * I + c) = make_float4(y0, y1, y2, y3);
         if (hi) {
             uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
@@ -2343,8 +2343,8 @@ __global__ void __launch_bounds__(256) silu_mul_interleaved_kernel(const float* 
                     u.x += u2[q].x; u.y += u2[q].y; u.z += u2[q].z; u.w += u2[q].w;
                 }
         }
-        const float y0 = (g.x / (1.0f + __expf(-g.x))) * u.x, y1 = (g.y / (1.0f + __expf(-g.y))) * u.y;
-        const float y2 = (g.z / (1.0f + __expf(-g.z))) * u.z, y3 = (g.w / (1.0f + __expf(-g.w))) * u.w;
+        const float y0 = silu_mul(g.x, u.x), y1 = silu_mul(g.y, u.y);
+        const float y2 = silu_mul(g.z, u.z), y3 = silu_mul(g.w, u.w);
         uint16_t h0, h1, h2, h3, l0, l1, l2, l3;
         split_bf16(y0, h0, l0); split_bf16(y1, h1, l1); split_bf16(y2, h2, l2); split_bf16(y3, h3, l3);
         const size_t o = out_packed ? xpack_off(r, c, I >> 5) : (size_t)r * I + c;

@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float g = acc[2 * pr][b][r], u = acc[2 * pr + 1][b][r];
-                        split_bf16((g / (1.0f + __expf(-g))) * u, h[r], l[r]);
+                        split_bf16(silu_mul(g, u), h[r], l[r]);
                     }
                     const size_t xo = a.act_packed ? xpack_off(row, f0, I >> 5) : (size_t)row * I + f0;
                     *reinterpret_cast<uint2*>(a.act_hi + xo) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
