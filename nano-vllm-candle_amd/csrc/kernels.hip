@@ -1430,8 +1430,8 @@ hipError_t launch_add_rmsnorm(const NormArgs& a, int rows, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     if (a.out_packed && a.xh && a.xl && !a.y && !a.row_idx && a.H % 32 == 0 && rows >= 1024) {  // prompt chunk, fragment-order planes
         const int KT = a.H / 32, tiles = (rows + 15) / 16;
-        if (KT <= 32) { add_rmsnorm_rows16_kernel<4, 8><<<tiles, 256, 0, s>>>(a, rows); return hipGetLastError(); }
-        if (KT <= 64) { add_rmsnorm_rows16_kernel<8, 8><<<tiles, 512, 0, s>>>(a, rows); return hipGetLastError(); }
+        if (KT <= 32) { add_rmsnorm_rows16_kernel<16, 2><<<tiles, 1024, 0, s>>>(a, rows); return hipGetLastError(); }  // about one tile per CU: many waves keep more loads in flight
+        if (KT <= 64) { add_rmsnorm_rows16_kernel<16, 4><<<tiles, 1024, 0, s>>>(a, rows); return hipGetLastError(); }
         if (KT <= 160) { add_rmsnorm_rows16_kernel<16, 10><<<tiles, 1024, 0, s>>>(a, rows); return hipGetLastError(); }
     }
     if (rows <= 128 && a.H >= 2048) add_rmsnorm_kernel<1024><<<rows, 1024, 0, s>>>(a);
