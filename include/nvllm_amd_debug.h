@@ -32,7 +32,8 @@ int nvllm_profile_read(nvllm_model* m, double* total_ms, int64_t* launches);
  * GEMM's in-launch split-K combine epilogues (fewer launches; measured slower on MI355X than slabs + a consumer launch). */
 int nvllm_debug_set_option(nvllm_model* m, const char* name, int value);
 
-/* counters for tests: "oneshot_calls" = all-reduces run on the one-shot device path by this model's context */
+/* counters for tests: "oneshot_calls" = all-reduces run on the one-shot device path by this model's context;
+ * "tile_gemm_launches" = projections run by the prefill tile GEMM */
 int nvllm_debug_get_counter(nvllm_model* m, const char* name, int64_t* value);
 
 /* Diagnostic build only (make -C nano-vllm-candle_amd/csrc stamps -> libnvllm_amd_stamps.so, select it with NVLLM_LIB):

@@ -492,6 +492,7 @@ struct nvllm_model {
     unsigned long long* stamps = nullptr;
     bool stamps_on = false;
     int stamp_launch = 0;
+    int64_t tile_launches = 0;  // projections run by the tile GEMM so far (tests assert the path they force was taken)
 
     // per-kernel-class HIP-event timing (bench roofline leg); 0 = off
     int prof_kind = 0;
@@ -1307,6 +1308,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
     const bool t_o = o_ks > 0 && (size_t)o_ks * R * H <= m->slab_floats;
     const bool t_gu = tile_on && gemm_tile_ok(R, 2 * m->I_l, H, 2, tmin);
     const bool t_down = t_gu && m->I_l % 32 == 0 && d_ks > 0 && (size_t)d_ks * R * H <= m->slab_floats;
+    m->tile_launches += (int64_t)m->L * ((int)t_qkv + (int)t_o + (int)t_gu + (int)t_down);
     for (int l = 0; l < m->L; ++l) {
         const LayerW& w = m->layers[l];
         NormArgs na;
@@ -1815,10 +1817,12 @@ extern "C" int nvllm_debug_set_option(nvllm_model* m, const char* name, int valu
     return fail(m->ctx, NVLLM_EINVAL, "unknown option '%s'", name);
 }
 
-// counters for tests: "oneshot_calls" = all-reduces this model's context has run on the one-shot device path
+// counters for tests: "oneshot_calls" = all-reduces this model's context has run on the one-shot device path;
+// "tile_gemm_launches" = projections this model has run on the prefill tile GEMM
 extern "C" int nvllm_debug_get_counter(nvllm_model* m, const char* name, int64_t* value) {
     if (!m || !name || !value) return NVLLM_EINVAL;
     if (!strcmp(name, "oneshot_calls")) { *value = (int64_t)m->ctx->os_calls; return NVLLM_OK; }
+    if (!strcmp(name, "tile_gemm_launches")) { *value = m->tile_launches; return NVLLM_OK; }
     return fail(m->ctx, NVLLM_EINVAL, "unknown counter '%s'", name);
 }
 

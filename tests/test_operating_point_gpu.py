@@ -93,6 +93,7 @@ def test_0_6b_full_depth_prefill_through_the_tile_gemm_vs_oracle(pkg, ctx, oracl
             check_rows(f"0.6B x28 layers, tile GEMM prefill (fuse_qk={fuse_qk}), contexts {[len(s) for s in seqs]}, step {step}", ids, lg, rid, rlg)
         for s, t in zip(seqs, ids):
             s.append(int(t))
+    assert m.counter("tile_gemm_launches") == 4 * cfg.num_hidden_layers  # the one prompt chunk, all four projections
     m.close()
 
 

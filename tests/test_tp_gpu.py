@@ -12,7 +12,7 @@ from tests.util import LOGITS_TOL, oracle_config, row_rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _run_tp(pkg, cfg, tp, seqs, steps, group):
+def _run_tp(pkg, cfg, tp, seqs, steps, group, options=None, max_batched_tokens=40):
     results = [None] * tp
     errors = []
 
@@ -20,7 +20,9 @@ def _run_tp(pkg, cfg, tp, seqs, steps, group):
         try:
             ctx = pkg.Context(0, tp_rank=rank, tp_size=tp, loopback_group=group)
             m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=4, ctx=ctx)
-            m.kv_alloc(8, 4, 40)
+            for k, v in (options or {}).items():
+                m.set_option(k, v)
+            m.kv_alloc(8, 4, max_batched_tokens)
             my = [list(s) for s in seqs]
             out = []
             for step in range(steps):
@@ -29,7 +31,7 @@ def _run_tp(pkg, cfg, tp, seqs, steps, group):
                 for s, t in zip(my, ids):
                     s.append(int(t))
             nxt = m.decode_next()[:len(my)].copy()  # device-feedback path under TP
-            results[rank] = (out, nxt)
+            results[rank] = (out, nxt, m.counter("tile_gemm_launches"))
             m.close()
             ctx.close()
         except Exception as e:  # noqa: BLE001
@@ -70,3 +72,30 @@ def test_tp_equals_tp1(tp, kw, oracle):
     rid, _ = om.run_greedy(ref_seqs)
     for rank in range(tp):
         assert res[rank][1].tolist() == rid.tolist()
+
+
+@pytest.mark.parametrize("fuse_qk", [1, 0])
+def test_tp_prompt_chunk_through_the_tile_gemm(oracle, fuse_qk):
+    # the driver's tensor-parallel leg prefills 4096-row chunks, i.e. the tile GEMM (tile_gemm.hip) on per-rank shard
+    # shapes with the all-reduce behind o_proj / down_proj: forced here at TP = 2 on a model whose shards fit its blocks
+    # (head_dim 128: the QKV epilogue variant too), 390 prompt rows in one chunk, then decode on the cache it filled
+    import nano_vllm_candle_amd as pkg
+
+    cfg = pkg.Qwen3Config.tiny(hidden_size=512, num_attention_heads=8, num_key_value_heads=4, head_dim=128,
+                               intermediate_size=1024, num_hidden_layers=2, vocab_size=2048)
+    rng = np.random.default_rng(11)
+    seqs = [rng.integers(0, cfg.vocab_size, n).tolist() for n in (150, 97, 143)]
+    steps, tp = 3, 2
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(4)
+    res = _run_tp(pkg, cfg, tp, seqs, steps, f"gtile{fuse_qk}", options={"tile_min_wgs": 1, "tile_fuse_qk": fuse_qk},
+                  max_batched_tokens=512)
+    assert all(r[2] == 4 * cfg.num_hidden_layers for r in res), [r[2] for r in res]  # all four projections of the prompt chunk
+    ref_seqs = [list(s) for s in seqs]
+    for step in range(steps):
+        rid, rlg = om.run_greedy(ref_seqs)
+        for rank in range(tp):
+            ids, lg = res[rank][0][step]
+            assert row_rel_err(lg, rlg) < LOGITS_TOL, (rank, step, row_rel_err(lg, rlg))
+            assert ids.tolist() == rid.tolist(), (rank, step)
+        for s, t in zip(ref_seqs, rid):
+            s.append(int(t))
