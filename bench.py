@@ -142,6 +142,42 @@ def run_tp_extra(pkg, torch, dist, a, rank, world, local_rank):
            "ms_per_step": dt * 1e3 / steps, "per_rank_bytes_per_step": byts / steps,
            "per_rank_hbm_frac": (byts / steps) / (dt / steps) / 1e9 / HBM_PEAK_GBS,
            "collectives": "2 RCCL all-reduce(sum) of [batch, hidden] f32 per layer + (max,idx) all-gather" if world > 1 else "none"}
+    if world > 1 and rank == 0:
+        print("TP_LEG_RESULT " + json.dumps(res), flush=True)  # on record before the optional trial below
+    if world > 1 and not os.environ.get("NVLLM_BENCH_SKIP_ONESHOT"):
+        # Trial of the opt-in one-shot all-reduce (csrc/oneshot.hip) on the SAME group: greedy ids of a replay must match
+        # the RCCL replay, then the same timed loop.  Everything here may fail or time out without touching `res` above.
+        try:
+            def replay(n):
+                model.kv_alloc(num_blocks=B * (-(-(P + steps + warm + 4) // 256)) + 2, max_seqs=B, max_batched_tokens=4096)
+                first = model.step(list(range(B)), prompts, is_prefill=True)[0].copy()
+                return [first] + [model.decode_next()[:B].copy() for _ in range(n)]
+
+            ref_ids = replay(8)
+            model.set_option("oneshot_allreduce", 1)
+            os_ids = replay(8)
+            calls = model.counter("oneshot_calls")
+            match = float(np.mean([np.mean(x == y) for x, y in zip(ref_ids, os_ids)]))
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                model.decode_next()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            dt2 = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([dt2], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt2 = float(t.item())
+            res["oneshot_allreduce_trial"] = {
+                "active": calls > 0, "device_allreduces": calls, "ms_per_step": dt2 * 1e3 / steps, "tokens_per_s": B * steps / dt2,
+                "greedy_ids_equal_to_rccl_run": match,
+                "note": "opt-in path (NVLLM_ONESHOT_AR=1); ids of prefill + 8 decode steps compared with the RCCL replay (sum order differs: rare ties may flip)"}
+        except Exception as e:  # noqa: BLE001
+            res["oneshot_allreduce_trial"] = {"error": repr(e)[:300]}
     model.close()
     ctx.close()
     return res
@@ -455,13 +491,18 @@ def main():
         try:
             cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=a.tp_timeout)
             for line in cp.stdout.splitlines():
-                if line.startswith("TP_LEG_RESULT "):
+                if line.startswith("TP_LEG_RESULT "):  # the last one wins: it carries the one-shot trial when that finished
                     tp_res = json.loads(line[len("TP_LEG_RESULT "):])
             if "error" in tp_res and rank == 0:
                 tp_res["error"] = f"child exit {cp.returncode}: " + (cp.stderr.strip().splitlines() or ["?"])[-1][:300]
         except subprocess.TimeoutExpired as e:
             tail = (e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")).strip().splitlines()
             tp_res = {"model": a.tp_model, "tp": world, "error": f"timed out after {a.tp_timeout} s: " + (tail[-1][:200] if tail else "")}
+            so = e.stdout.decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or "")
+            for line in so.splitlines():  # the RCCL result is printed before the one-shot trial: a trial that hangs costs only itself
+                if line.startswith("TP_LEG_RESULT "):
+                    tp_res = json.loads(line[len("TP_LEG_RESULT "):])
+                    tp_res["oneshot_allreduce_trial"] = {"error": f"child timed out after {a.tp_timeout} s during the trial"}
         except Exception as e:  # noqa: BLE001
             tp_res = {"model": a.tp_model, "tp": world, "error": repr(e)[:300]}
         out["tp_scaling"] = tp_res

@@ -39,6 +39,7 @@ __global__ void __launch_bounds__(256) oneshot_push_kernel(const float4* __restr
 // one wave: lane r waits for rank r's flag.  Bounded: a peer that never arrives leaves *err = 1 (the step's results are
 // then wrong and the host reports it) instead of a kernel that never ends.
 __global__ void __launch_bounds__(64) oneshot_wait_kernel(const uint32_t* flags, int tp, int gen, uint32_t seq, int* err, long long max_spins) {
+    if (*reinterpret_cast<volatile int*>(err)) return;  // an earlier wait of this step already gave up: do not spin again
     if ((int)threadIdx.x < tp) {
         const uint32_t* f = flags + gen * tp + threadIdx.x;
         long long spins = 0;
@@ -59,7 +60,8 @@ hipError_t launch_oneshot_push(const float* src, size_t n, const OneShotPeers& p
 }
 
 hipError_t launch_oneshot_wait(const uint32_t* flags, int tp, int gen, uint32_t seq, int* err, hipStream_t s) {
-    oneshot_wait_kernel<<<1, 64, 0, s>>>(flags, tp, gen, seq, err, 20000000LL);  // ~ seconds, not forever
+    static const long long max_spins = getenv("NVLLM_ONESHOT_SPINS") ? atoll(getenv("NVLLM_ONESHOT_SPINS")) : 20000000LL;  // ~ seconds, not forever
+    oneshot_wait_kernel<<<1, 64, 0, s>>>(flags, tp, gen, seq, err, max_spins);
     return hipGetLastError();
 }
 
