@@ -447,7 +447,7 @@ struct nvllm_model {
     // step buffers
     uint32_t* d_ids = nullptr;
     int *d_pos = nullptr, *d_slot = nullptr, *d_tile_row0 = nullptr, *d_tile_nrows = nullptr, *d_tile_slot = nullptr,
-        *d_last_rows = nullptr, *d_tile_order = nullptr, *d_tile_last = nullptr;
+        *d_last_rows = nullptr, *d_tile_order = nullptr, *d_tile_last = nullptr, *d_group_order = nullptr;
     float *resid = nullptr, *slabs = nullptr, *qbuf = nullptr, *logits = nullptr, *d_maxval = nullptr, *red = nullptr;
     bf16_bits *xh = nullptr, *xl = nullptr, *xh2 = nullptr, *xl2 = nullptr, *ctxh = nullptr, *ctxl = nullptr;
     float *ssqA = nullptr, *ssqB = nullptr;  // deferred-norm partial sums of squares [groups][kFusedMaxRows]
@@ -603,10 +603,10 @@ static void free_kv(nvllm_model* m) {
     for (auto p : m->vcache) (void)hipFree(p);
     m->kcache.clear(); m->vcache.clear();
     void* ptrs[] = {m->d_block_tables, m->d_ids, m->d_pos, m->d_slot, m->d_tile_row0, m->d_tile_nrows, m->d_tile_slot,
-                    m->d_last_rows, m->d_tile_order, m->d_tile_last, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->xh2, m->xl2, m->ctxh, m->ctxl, m->ssqA, m->ssqB, m->d_next,
+                    m->d_last_rows, m->d_tile_order, m->d_tile_last, m->d_group_order, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->xh2, m->xl2, m->ctxh, m->ctxl, m->ssqA, m->ssqB, m->d_next,
                     m->part_val, m->part_idx, m->argmax_scratch, m->attn_po, m->attn_pml, m->tap_h, m->tap_res, m->cosv, m->sinv, m->tickets, m->qkv_out, m->d_keys, m->d_temps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    m->d_block_tables = nullptr; m->d_ids = nullptr; m->d_pos = m->d_slot = m->d_tile_row0 = m->d_tile_nrows = m->d_tile_slot = m->d_last_rows = m->d_tile_order = m->d_tile_last = nullptr;
+    m->d_block_tables = nullptr; m->d_ids = nullptr; m->d_pos = m->d_slot = m->d_tile_row0 = m->d_tile_nrows = m->d_tile_slot = m->d_last_rows = m->d_tile_order = m->d_tile_last = m->d_group_order = nullptr;
     m->resid = m->slabs = m->qbuf = m->logits = m->d_maxval = m->red = nullptr; m->xh = m->xl = m->xh2 = m->xl2 = m->ctxh = m->ctxl = nullptr; m->ssqA = m->ssqB = nullptr; m->d_next = nullptr; m->part_val = nullptr; m->part_idx = nullptr; m->argmax_scratch = nullptr; m->attn_po = m->attn_pml = nullptr;
     m->tap_h = m->tap_res = nullptr; m->cosv = m->sinv = nullptr; m->tickets = nullptr; m->qkv_out = nullptr; m->d_keys = nullptr; m->d_temps = nullptr;
     if (m->h_stage) (void)hipHostFree(m->h_stage);
@@ -878,6 +878,7 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->d_last_rows, (size_t)max_seqs);
     if (!rc) rc = dmalloc(ctx, &m->d_tile_order, 4 * R);
     if (!rc) rc = dmalloc(ctx, &m->d_tile_last, 4 * R);
+    if (!rc) rc = dmalloc(ctx, &m->d_group_order, R + 4);
     if (!rc) rc = dmalloc(ctx, &m->resid, R * m->H);
     if (!rc) rc = dmalloc(ctx, &m->slabs, m->slab_floats);
     if (!rc) rc = dmalloc(ctx, &m->qbuf, R * m->nh_l * m->hd);
@@ -914,7 +915,7 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (!rc) rc = dmalloc(ctx, &m->argmax_scratch, (size_t)max_seqs + 1);
     if (!rc) HIPCHK(ctx, hipMemsetAsync(m->argmax_scratch, 0, ((size_t)max_seqs + 1) * 8, ctx->stream));
     if (rc) return rc;
-    m->h_stage_bytes = (R * 23 + (size_t)max_seqs * 4) * sizeof(int) + 256;
+    m->h_stage_bytes = (R * 24 + (size_t)max_seqs * 4) * sizeof(int) + 256;
     HIPCHK(ctx, hipHostMalloc(&m->h_stage, m->h_stage_bytes, hipHostMallocDefault));
     // RoPE table: rotary_embedding.rs:56-80 (f32: inv_freq = 1/base^(2j/hd); angle = pos * inv_freq)
     m->rope_len = std::min(m->cfg.max_position_embeddings, m->max_blocks * kBlockTokens);
@@ -1189,6 +1190,7 @@ static int forward_chunk_fused(nvllm_model* m, const FusedPlan& fp, int R, int n
         aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
         aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
         aa.tile_last = m->d_tile_last;
+        if (qt == 2) aa.group_order = m->d_group_order;
         aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->ctxh; aa.out_lo = m->ctxl; aa.out_packed = packed;
         if (qt == 1) aa.tile_order = m->d_tile_order;
         if (fuse_qk) {
@@ -1285,6 +1287,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
     const float eps = (float)m->cfg.rms_norm_eps;
     const int NQ = (m->nh_l + 2 * m->kv_l) * hd;
     const float* prev = nullptr;  // output of the previous layer's MLP (slabs or reduced)
+    m->stamp_launch = 0;
     int prev_ns = 1;
     int64_t prev_stride = 0;
     m->tap_rows = R;
@@ -1342,6 +1345,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
         aa.tile_row0 = m->d_tile_row0; aa.tile_nrows = m->d_tile_nrows; aa.tile_slot = m->d_tile_slot; aa.pos = m->d_pos;
         aa.tile_last = m->d_tile_last;
+        if (qt == 2) aa.group_order = m->d_group_order;
         aa.nh_l = m->nh_l; aa.gqa = m->gqa; aa.out_hi = m->xh; aa.out_lo = m->xl; aa.out_packed = packed || t_o;
         if (qt == 1) aa.tile_order = m->d_tile_order;
         if (fuse_qk) {
@@ -1353,6 +1357,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
             aa.part_tiles = m->attn_part_tiles; aa.max_parts = kAttnMaxParts; aa.part_o = m->attn_po; aa.part_ml = m->attn_pml;
             parts_max = m->attn_parts_max;
         }
+        STAMPS(aa, m);
         if (qt == 2) PROF(m, PROF_ATTN, launch_attn_prefill(aa, n_tiles, s));
         else PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
         // output projection (qwen3.rs:278) + TP all-reduce
@@ -1560,6 +1565,19 @@ static int upload_chunk(nvllm_model* m, const RowPlan& p, int r0, int R, int t0,
         HIPCHK(ctx, hipMemcpyAsync(m->d_last_rows, h_last, last_local.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(m->d_tile_order, h_ord, (size_t)T * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(m->d_tile_last, h_tl, (size_t)T * 4, hipMemcpyHostToDevice, s));
+    if (T % kPrefillTileGroup == 0) {  // prefill attention: groups of four q-tiles, longest context first
+        int* h_go = h_tl + T;
+        const int G = T / kPrefillTileGroup;
+        std::vector<int> glast(G);
+        for (int g = 0; g < G; ++g) {
+            int mx = -1;
+            for (int k = 0; k < kPrefillTileGroup; ++k) mx = std::max(mx, h_tl[g * kPrefillTileGroup + k]);
+            glast[g] = mx;
+            h_go[g] = g;
+        }
+        std::stable_sort(h_go, h_go + G, [&](int x, int y) { return glast[x] > glast[y]; });
+        HIPCHK(ctx, hipMemcpyAsync(m->d_group_order, h_go, (size_t)G * 4, hipMemcpyHostToDevice, s));
+    }
     return NVLLM_OK;
 }
 

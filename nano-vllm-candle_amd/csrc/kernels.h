@@ -208,6 +208,8 @@ struct AttnArgs {
     const int* tile_row0 = nullptr;    // per q-tile: first row, #rows, sequence slot
     const int* tile_nrows = nullptr;
     const int* tile_slot = nullptr;
+    const int* group_order = nullptr;  // optional (prefill kernel): tile groups (4 q-tiles) sorted longest context first; the
+                                       // workgroups beyond the resident set then are the short ones, not whatever came last
     const int* tile_last = nullptr;    // optional (prefill kernel): position of the tile's last row, -1 for an empty tile;
                                        // saves the kernel a chain of dependent metadata loads per workgroup
     const int* pos = nullptr;          // [rows]

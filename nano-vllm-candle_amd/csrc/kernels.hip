@@ -1982,12 +1982,19 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
     uint4* lds = reinterpret_cast<uint4*>(smem_raw);  // [3 stages][TILE_FRAGS][64]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, grp = lane >> 4;
-    const int kh = blockIdx.y;
-    const int tile = (int)blockIdx.x * NWV + wave;
+    // 1-D grid, kv heads fastest, groups in the host's longest-first order: the dispatcher hands out workgroups in index
+    // order, so what is left over when all CU slots are taken (528 workgroups for 512 slots on a 4096-row chunk) must
+    // be the short contexts -- in launch order the late starters were long ones and set the kernel's end (stamps:
+    // start + 16 us, end 36.7 us against 30 us for the longest workgroup of the first wave)
+    const int kv_heads = a.kv.kv_l;
+    const int gi = (int)blockIdx.x / kv_heads, kh = (int)blockIdx.x - gi * kv_heads;
+    const int grp4 = a.group_order ? __builtin_amdgcn_readfirstlane(a.group_order[gi]) : gi;
+    const int tile = grp4 * NWV + wave;
+    NVLLM_STAMP(a, 0);
     // wave-uniform values are made scalar explicitly (readfirstlane): the block-table lookup in stage() is then an s_load
     // on the scalar counter; as a vector load it made every iteration wait vmcnt(0) -- for the lookup's own round trip
     // AND for the K/V tiles meant to stay in flight
-    const int slot = __builtin_amdgcn_readfirstlane(a.tile_slot[(int)blockIdx.x * NWV]);  // all four tiles belong to one sequence
+    const int slot = __builtin_amdgcn_readfirstlane(a.tile_slot[grp4 * NWV]);  // all four tiles belong to one sequence
     const int row0 = __builtin_amdgcn_readfirstlane(a.tile_row0[tile]), nrows = __builtin_amdgcn_readfirstlane(a.tile_nrows[tile]);
     const int gqa = a.gqa, tpq = 16 / gqa;
     const int kv_l = a.kv.kv_l;
@@ -2005,7 +2012,7 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
     const int first_pos = nrows > 0 ? __builtin_amdgcn_readfirstlane(a.pos[row0]) : 0;  // every row of this wave is at or after it
     int my_last, wg_last;
     if (a.tile_last) {  // one 16-byte scalar load instead of twelve dependent ones
-        const int4 tl = *reinterpret_cast<const int4*>(a.tile_last + (size_t)blockIdx.x * NWV);
+        const int4 tl = *reinterpret_cast<const int4*>(a.tile_last + (size_t)grp4 * NWV);
         const int l0 = __builtin_amdgcn_readfirstlane(tl.x), l1 = __builtin_amdgcn_readfirstlane(tl.y),
                   l2 = __builtin_amdgcn_readfirstlane(tl.z), l3 = __builtin_amdgcn_readfirstlane(tl.w);
         const int mine = wave == 0 ? l0 : wave == 1 ? l1 : wave == 2 ? l2 : l3;
@@ -2017,7 +2024,7 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
         wg_last = my_last;
 #pragma unroll
         for (int w = 0; w < NWV; ++w) {
-            const int t2 = (int)blockIdx.x * NWV + w, n2 = __builtin_amdgcn_readfirstlane(a.tile_nrows[t2]);
+            const int t2 = grp4 * NWV + w, n2 = __builtin_amdgcn_readfirstlane(a.tile_nrows[t2]);
             if (n2 > 0) wg_last = max(wg_last, __builtin_amdgcn_readfirstlane(a.pos[__builtin_amdgcn_readfirstlane(a.tile_row0[t2]) + n2 - 1]) >> 5);
         }
     }
@@ -2082,6 +2089,13 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
 #pragma unroll
         for (int d = 0; d < DT; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    NVLLM_STAMP(a, 1);
+#ifdef NVLLM_STAMPS
+    if (a.stamps && lane == 0) {  // iteration counts ride in two stamp slots
+        a.stamps[((size_t)blockIdx.x * 16 + wave) * 8 + 5] = (unsigned long long)(wg_last + 1);
+        a.stamps[((size_t)blockIdx.x * 16 + wave) * 8 + 6] = (unsigned long long)(my_last + 1);
+    }
+#endif
     int buf = 0;
     for (int kt = 0; kt <= wg_last; ++kt, buf = buf == 2 ? 0 : buf + 1) {
         // every wave waits for its own copies of tile kt (all but the TILE_FRAGS / NWV newest: those are tile kt+1),
@@ -2172,6 +2186,7 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
             for (int t = 0; t < QT; ++t) o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fv, P[t], o[t][d], 0, 0, 0);
         }
     }
+    NVLLM_STAMP(a, 2);
     // every wave owns its rows for the whole context: normalise and store (D[dim 4*grp+reg][q row l15] -> out[row][head dims])
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -2194,6 +2209,7 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
             }
         }
     }
+    NVLLM_STAMP(a, 3);
 }
 
 // merge the split-KV partials of one (row, q head): one wave each, lane = 2 (HD 128) or 1 (HD 64) dims
@@ -2251,7 +2267,7 @@ static hipError_t attn_launch_t(const AttnArgs& a, int n_tiles, int grid_z, hipS
 hipError_t launch_attn_prefill(const AttnArgs& a, int n_tiles, hipStream_t s) {
     if (n_tiles <= 0) return hipSuccess;
     if (n_tiles % 4 || a.gqa < 1 || a.gqa > 16 || (a.kv.hd != 128 && a.kv.hd != 64)) return hipErrorInvalidValue;
-    dim3 grid(n_tiles / 4, a.kv.kv_l);
+    dim3 grid((n_tiles / 4) * a.kv.kv_l);
     if (a.kv.hd == 128) {
         const size_t lds = (size_t)3 * (2 * 4 + 8) * 1024;
         attn_prefill_kernel<128, 2><<<grid, 256, lds, s>>>(a);
