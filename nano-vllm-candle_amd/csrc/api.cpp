@@ -1576,6 +1576,10 @@ static int upload_chunk(nvllm_model* m, const RowPlan& p, int r0, int R, int t0,
             h_go[g] = g;
         }
         std::stable_sort(h_go, h_go + G, [&](int x, int y) { return glast[x] > glast[y]; });
+        // every other block of 256 workgroups (256 / kv heads groups) backwards: workgroups i and i + 256 tend to share
+        // a CU, so the longest context gets the shortest of the next block as its neighbour and the CU to itself sooner
+        const int per = std::max(1, 256 / std::max(1, m->kv_l));
+        for (int b0 = per; b0 < G; b0 += 2 * per) std::reverse(h_go + b0, h_go + std::min(G, b0 + per));
         HIPCHK(ctx, hipMemcpyAsync(m->d_group_order, h_go, (size_t)G * 4, hipMemcpyHostToDevice, s));
     }
     return NVLLM_OK;
