@@ -1855,6 +1855,10 @@ extern "C" int nvllm_debug_stamps(nvllm_model* m, int enable) {
     if (enable && !m->stamps) HIPCHK(m->ctx, hipMalloc((void**)&m->stamps, kStampLaunches * kStampStride * 8));
     if (enable) HIPCHK(m->ctx, hipMemset(m->stamps, 0, kStampLaunches * kStampStride * 8));
     m->stamps_on = enable != 0;
+    // enable == 2: the tile GEMM launches of the following steps record instead of the attention / decode kernels
+    // (same buffer, launch index = order of the tile launches)
+    nvllm::tile_gemm_stamps_arm(enable == 2 ? m->stamps : nullptr, kStampLaunches);
+    if (enable == 2) m->stamps_on = false;
     return NVLLM_OK;
 #else
     return fail(m->ctx, NVLLM_ESTATE, "library built without NVLLM_STAMPS (make -C nano-vllm-candle_amd/csrc stamps)");

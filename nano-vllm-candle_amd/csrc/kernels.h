@@ -186,6 +186,10 @@ hipError_t launch_gemm_tile(const bf16_bits* xh, const bf16_bits* xl, const Pack
 bool gemm_tile_qkv_ok(int M, int N, int K, int hd, int min_wgs);
 hipError_t launch_gemm_tile_qkv(const bf16_bits* xh, const bf16_bits* xl, const PackedW& w, int M, const QkvArgs& qa, int min_wgs,
                                 hipStream_t s);
+#ifdef NVLLM_STAMPS
+void tile_gemm_stamps_arm(unsigned long long* base, int max_launches);  // diagnostic build
+int tile_gemm_stamps_count();
+#endif
 hipError_t launch_xpack_plane(const bf16_bits* src, bf16_bits* dst, int M, int K, hipStream_t s);
 
 // ---- one-shot all-reduce for TP decode (oneshot.hip) -----------------------------------------------------------

@@ -43,7 +43,18 @@ struct TileArgs {
     int MB = 0, NB = 0;         // row blocks, feature blocks
     int map = 0;                // 0: id -> (nb fastest); 1: blocks of one XCD share rows; 2: share features
     QkvArgs q;                  // MODE 3
+#ifdef NVLLM_STAMPS
+    unsigned long long* stamps = nullptr;  // diagnostic build: [workgroup][16 waves][8 points] of s_memrealtime
+#endif
 };
+
+#ifdef NVLLM_STAMPS
+// diagnostic build only: the next tile launches record their stamps here, one kStride block per launch (tools/stamp_tile_gemm.py)
+static unsigned long long* g_tile_stamps = nullptr;
+static int g_tile_stamp_launch = 0, g_tile_stamp_max = 0;
+void tile_gemm_stamps_arm(unsigned long long* base, int max_launches) { g_tile_stamps = base; g_tile_stamp_launch = 0; g_tile_stamp_max = max_launches; }
+int tile_gemm_stamps_count() { return g_tile_stamp_launch; }
+#endif
 
 // WN = waves along the features (2: 256 rows x 32*NTW features; 4: 128 rows x 64*NTW features -- the narrow-output shape,
 // N = hidden size, where 256-row tiles cannot fill the chip)
@@ -73,6 +84,22 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
         if (mb >= a.MB || nb >= a.NB) return;  // whole workgroup, before any barrier
     }
     const int mtiles = (a.M + 15) >> 4;
+    NVLLM_STAMP(a, 0);
+    // MODE 3: position and cache block of this lane's four tokens, fetched NOW (two dependent loads each) so that they
+    // land under the K loop; in the epilogue they were 8 us of latency chain per workgroup (stamps)
+    [[maybe_unused]] int e_pos[4], e_blk[4], e_slot0 = 0;
+    [[maybe_unused]] bool e_one_seq = true;  // this lane's four tokens belong to one sequence
+    if constexpr (MODE == 3) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int rowc = min(mb * (WM * 64) + wm * 64 + b * 16 + l15, a.M - 1);
+            const int sl = a.q.slot[rowc];
+            if (b == 0) e_slot0 = sl;
+            e_one_seq = e_one_seq && sl == e_slot0;
+            e_pos[b] = a.q.pos[rowc];
+            e_blk[b] = a.q.block_tables[(size_t)sl * a.q.max_blocks + (e_pos[b] >> 8)];
+        }
+    }
 
     // DMA sources of this wave's copies at k-tile 0, without the lane part (advance: 64 uint4 per k-tile).  Row tiles
     // past the end are clamped to the last one: their products land in columns of D that are never stored.
@@ -127,6 +154,7 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
     issue(0, 0);
     issue(1, 1);
     publish();
+    NVLLM_STAMP(a, 1);
     bf16x8 WA[NTW], WB[NTW], xh0, xl0, xh1, xl1;
 #pragma unroll
     for (int j = 0; j < NTW; ++j) NVLLM_WF(WA[j], w_cur, j);
@@ -190,6 +218,7 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
 #undef NVLLM_LDSR
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the two issues past the end, the last prefetch reads
 #undef NVLLM_LGKM
+    NVLLM_STAMP(a, 2);
 
     // D[feature 4*grp + r][token l15]
     const int nt0 = nb * FRW + wn * NTW;
@@ -212,11 +241,65 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
         const QkvArgs& q = a.q;
         const int hh = wn == 0 ? nb : a.NB + nb;  // this wave's head: [q heads | k heads | v heads]
         const int nh = q.nh_l, kvl = q.kv.kv_l;
+        // V heads: in the cache's PV fragment order TOKENS are the fast index (8 per 16-byte slot), while a lane here
+        // holds 4 features of ONE token -- stored directly that is 128 two-byte stores per lane, and the V workgroups set
+        // the kernel's end (stamps: epilogue 20 us against 13).  When the wave's 64 rows are consecutive positions of one
+        // sequence (the usual case) the tile goes through LDS instead -- the ring is free now -- as Vt[feature][token +
+        // pos % 4], so that every aligned group of four positions is one 8-byte word: 34 eight-byte stores per lane.
+        asm volatile("s_barrier" ::: "memory");  // every wave has finished reading the ring (uniform: all modes-3 waves)
+        bool v_done = false;
+        if (hh >= nh + kvl) {
+            const int nvalid = min(64, a.M - row0);
+            const int P0 = __builtin_amdgcn_readfirstlane(e_pos[0]);
+            bool okl = e_one_seq && e_slot0 == __builtin_amdgcn_readfirstlane(e_slot0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) okl = okl && (b * 16 + l15 >= nvalid || e_pos[b] == P0 + b * 16 + l15);
+            if (nvalid > 0 && __builtin_amdgcn_ballot_w64(!okl) == 0) {
+                constexpr int LDV = 72;  // halves per feature row: 64 tokens + 3 shift, padded to a multiple of 4
+                _Float16* vt = reinterpret_cast<_Float16*>(smem_raw) + (size_t)wm * (128 * LDV);
+                const int sh = P0 & 3;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float ri = rownorm_rinv(q.rn, min(row0 + b * 16 + l15, a.M - 1));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vt[(j * 16 + grp * 4 + r) * LDV + b * 16 + l15 + sh] = f16_sat(acc[j][b][r] * ri);
+                }
+                const int blkA = __builtin_amdgcn_readfirstlane(e_blk[0]);                       // block of position P0
+                const int blkB = __builtin_amdgcn_readlane(e_blk[(nvalid - 1) >> 4], (nvalid - 1) & 15);  // ... of the last valid token
+                const int kvh = hh - nh - kvl;
+                for (int cq = 0; cq < 17; ++cq) {
+                    const int tfirst = 4 * cq - sh;  // token of the word's first column
+                    if (tfirst + 3 < 0 || tfirst >= nvalid) continue;
+                    const int p = P0 + tfirst;       // multiple of 4
+                    const int blk = (p >> 8) == (P0 >> 8) ? blkA : blkB;
+                    _Float16* vdst = reinterpret_cast<_Float16*>(q.kv.v) + (size_t)(blk * kvl + kvh) * kBlockTokens * 128;
+                    const int tib = p & 255, tile32 = tib >> 5, tt = tib & 31;
+                    const bool full = tfirst >= 0 && tfirst + 3 < nvalid;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int d = lane * 2 + e;
+                        const uint2 w = *reinterpret_cast<const uint2*>(vt + d * LDV + 4 * cq);
+                        const size_t off = ((size_t)(tile32 * 8 + (d >> 4)) * 64 + ((tt & 15) >> 2) * 16 + (d & 15)) * 8 + (tt >> 4) * 4;
+                        if (full) {
+                            *reinterpret_cast<uint2*>(vdst + off) = w;
+                        } else {
+                            const uint16_t hv[4] = {(uint16_t)(w.x & 0xffff), (uint16_t)(w.x >> 16), (uint16_t)(w.y & 0xffff), (uint16_t)(w.y >> 16)};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (tfirst + i >= 0 && tfirst + i < nvalid) reinterpret_cast<uint16_t*>(vdst)[off + i] = hv[i];
+                        }
+                    }
+                }
+                v_done = true;
+            }
+        }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int row = row0 + b * 16 + l15;
             const int rowc = min(row, a.M - 1);
-            const int pos = q.pos[rowc];
+            const int pos = e_pos[b];
             const float ri = rownorm_rinv(q.rn, rowc);  // deferred input norm (1 when the planes were normalised)
             if (hh < nh + kvl) {
                 float ss = 0.f;
@@ -255,7 +338,7 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
                             *reinterpret_cast<float4*>(qo + j * 16) = make_float4(acc[j][b][0] * q.q_scale, acc[j][b][1] * q.q_scale,
                                                                                  acc[j][b][2] * q.q_scale, acc[j][b][3] * q.q_scale);
                     } else {
-                        const int blk = q.block_tables[(size_t)q.slot[row] * q.max_blocks + (pos >> 8)];
+                        const int blk = e_blk[b];
                         _Float16* k = reinterpret_cast<_Float16*>(q.kv.k) + (size_t)(blk * kvl + (hh - nh)) * kBlockTokens * 128;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
@@ -265,8 +348,8 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
                         }
                     }
                 }
-            } else if (row < a.M) {  // V head: plain copy into the PV fragment order (tokens are the fast index there)
-                const int blk = q.block_tables[(size_t)q.slot[row] * q.max_blocks + (pos >> 8)];
+            } else if (row < a.M && !v_done) {  // V head, rows of several sequences in this wave: element-wise copy into the PV fragment order
+                const int blk = e_blk[b];
                 _Float16* v = reinterpret_cast<_Float16*>(q.kv.v) + (size_t)(blk * kvl + (hh - nh - kvl)) * kBlockTokens * 128;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
@@ -297,6 +380,7 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
             }
         }
     }
+    NVLLM_STAMP(a, 3);
 }
 
 // ---- host side -------------------------------------------------------------------------------------
@@ -346,6 +430,10 @@ static hipError_t tile_launch_t(TileArgs& a, int ks, hipStream_t s) {
     const size_t lds = (size_t)3 * FR * 1024;
     static std::atomic<uint64_t> lds_set{0};
     ensure_dyn_lds(reinterpret_cast<const void*>(gemm_tile_kernel<NTW, WN, MODE>), lds, lds_set);
+#ifdef NVLLM_STAMPS
+    if (g_tile_stamps && g_tile_stamp_launch < g_tile_stamp_max && (size_t)grid * ks <= 1024)
+        a.stamps = g_tile_stamps + (size_t)(g_tile_stamp_launch++) * ((size_t)1024 * 16 * 8);
+#endif
     gemm_tile_kernel<NTW, WN, MODE><<<dim3(grid, ks), 512, lds, s>>>(a);
     return hipGetLastError();
 }

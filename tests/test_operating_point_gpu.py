@@ -74,7 +74,7 @@ def test_0_6b_full_depth_long_contexts_vs_oracle(pkg, ctx, oracle_0_6b):
 
 @pytest.mark.parametrize("fuse_qk", [1, 0])
 def test_0_6b_full_depth_prefill_through_the_tile_gemm_vs_oracle(pkg, ctx, oracle_0_6b, fuse_qk):
-    # the same four prompts as one 1379-row chunk with every projection forced through the prefill tile GEMM
+    # four prompts as one 1379-row chunk with every projection forced through the prefill tile GEMM
     # (tile_gemm.hip; by default it takes over only when its 256-row tiles fill the chip, i.e. on ~4096-row chunks, which
     # the 8B batch-256 test below exercises): QKV, o_proj, gate/up + SiLU*mul and down_proj read planes in fragment order
     # written by the norm, the attention and the SwiGLU epilogue.  fuse_qk: q/k-norm + RoPE + the K/V cache write run in
@@ -85,7 +85,9 @@ def test_0_6b_full_depth_prefill_through_the_tile_gemm_vs_oracle(pkg, ctx, oracl
     m.set_option("tile_min_wgs", 1)
     m.set_option("tile_fuse_qk", fuse_qk)
     rng = np.random.default_rng(21)
-    seqs = [rng.integers(0, cfg.vocab_size, n).tolist() for n in (64, 292, 512, 511)]
+    # odd lengths: 64-row wave tiles then start at positions that are not multiples of 4 (the V store's LDS transpose
+    # shifts by pos % 4) and several of them straddle two sequences (element-wise fallback)
+    seqs = [rng.integers(0, cfg.vocab_size, n).tolist() for n in (61, 293, 510, 515)]
     for step in range(3):
         ids, lg = m.step([0, 1, 2, 3], seqs, step == 0, want_logits=True)
         if step in (0, 2):
