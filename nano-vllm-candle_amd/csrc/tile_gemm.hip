@@ -295,13 +295,22 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
                 v_done = true;
             }
         }
+        if (hh < nh + kvl) {
+            // q / k head.  cos / sin rows of the NEXT 16 tokens are fetched while the current 16 are rotated (two register
+            // sets, static indices); hoisting the norm weights as well spilled (256 registers + scratch)
+            const float* w = hh < nh ? q.qn : q.kn;
+            auto load_cs = [&](int pos, float4 (&cs)[4], float4 (&sn)[4]) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int row = row0 + b * 16 + l15;
-            const int rowc = min(row, a.M - 1);
-            const int pos = e_pos[b];
-            const float ri = rownorm_rinv(q.rn, rowc);  // deferred input norm (1 when the planes were normalised)
-            if (hh < nh + kvl) {
+                for (int j = 0; j < 4; ++j) {
+                    cs[j] = *reinterpret_cast<const float4*>(q.cos + (size_t)pos * 64 + j * 16 + grp * 4);
+                    sn[j] = *reinterpret_cast<const float4*>(q.sin + (size_t)pos * 64 + j * 16 + grp * 4);
+                }
+            };
+            auto tokens16 = [&](auto bc, const float4 (&cs)[4], const float4 (&sn)[4]) {
+                constexpr int b = decltype(bc)::value;
+                const int row = row0 + b * 16 + l15;
+                const int pos = e_pos[b];
+                const float ri = rownorm_rinv(q.rn, min(row, a.M - 1));  // deferred input norm (1 when the planes were normalised)
                 float ss = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
@@ -314,15 +323,11 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
                 ss += __shfl_xor(ss, 16);  // the four lane groups hold the other 96 features of this token
                 ss += __shfl_xor(ss, 32);
                 const float rinv = 1.0f / sqrtf(ss / 128.0f + q.eps);
-                const float* w = hh < nh ? q.qn : q.kn;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int d = j * 16 + grp * 4;
-                    const float4 w1 = *reinterpret_cast<const float4*>(w + d), w2 = *reinterpret_cast<const float4*>(w + 64 + d);
-                    const float4 cs = *reinterpret_cast<const float4*>(q.cos + (size_t)pos * 64 + d);
-                    const float4 sn = *reinterpret_cast<const float4*>(q.sin + (size_t)pos * 64 + d);
+                    const float4 w1 = *reinterpret_cast<const float4*>(w + j * 16 + grp * 4), w2 = *reinterpret_cast<const float4*>(w + 64 + j * 16 + grp * 4);
                     const float w1a[4] = {w1.x, w1.y, w1.z, w1.w}, w2a[4] = {w2.x, w2.y, w2.z, w2.w};
-                    const float ca[4] = {cs.x, cs.y, cs.z, cs.w}, sa[4] = {sn.x, sn.y, sn.z, sn.w};
+                    const float ca[4] = {cs[j].x, cs[j].y, cs[j].z, cs[j].w}, sa[4] = {sn[j].x, sn[j].y, sn[j].z, sn[j].w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float n1 = (acc[j][b][r] * rinv) * w1a[r], n2 = (acc[j + 4][b][r] * rinv) * w2a[r];
@@ -338,8 +343,7 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
                             *reinterpret_cast<float4*>(qo + j * 16) = make_float4(acc[j][b][0] * q.q_scale, acc[j][b][1] * q.q_scale,
                                                                                  acc[j][b][2] * q.q_scale, acc[j][b][3] * q.q_scale);
                     } else {
-                        const int blk = e_blk[b];
-                        _Float16* k = reinterpret_cast<_Float16*>(q.kv.k) + (size_t)(blk * kvl + (hh - nh)) * kBlockTokens * 128;
+                        _Float16* k = reinterpret_cast<_Float16*>(q.kv.k) + (size_t)(e_blk[b] * kvl + (hh - nh)) * kBlockTokens * 128;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
@@ -348,13 +352,29 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
                         }
                     }
                 }
-            } else if (row < a.M && !v_done) {  // V head, rows of several sequences in this wave: element-wise copy into the PV fragment order
-                const int blk = e_blk[b];
-                _Float16* v = reinterpret_cast<_Float16*>(q.kv.v) + (size_t)(blk * kvl + (hh - nh - kvl)) * kBlockTokens * 128;
+            };
+            float4 csA[4], snA[4], csB[4], snB[4];
+            load_cs(e_pos[0], csA, snA);
+            load_cs(e_pos[1], csB, snB);
+            tokens16(std::integral_constant<int, 0>{}, csA, snA);
+            load_cs(e_pos[2], csA, snA);
+            tokens16(std::integral_constant<int, 1>{}, csB, snB);
+            load_cs(e_pos[3], csB, snB);
+            tokens16(std::integral_constant<int, 2>{}, csA, snA);
+            tokens16(std::integral_constant<int, 3>{}, csB, snB);
+        } else if (!v_done) {  // V head, rows of several sequences in this wave: element-wise copy into the PV fragment order
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+            for (int b = 0; b < 4; ++b) {
+                const int row = row0 + b * 16 + l15;
+                if (row < a.M) {
+                    const float ri = rownorm_rinv(q.rn, row);
+                    const int pos = e_pos[b];
+                    _Float16* v = reinterpret_cast<_Float16*>(q.kv.v) + (size_t)(e_blk[b] * kvl + (hh - nh - kvl)) * kBlockTokens * 128;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[v_packed_offset(pos & 255, j * 16 + grp * 4 + r, 128)] = f16_sat(acc[j][b][r] * ri);
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[v_packed_offset(pos & 255, j * 16 + grp * 4 + r, 128)] = f16_sat(acc[j][b][r] * ri);
+                }
             }
         }
     } else {
