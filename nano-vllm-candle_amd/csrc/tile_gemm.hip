@@ -311,37 +311,35 @@ __global__ void __launch_bounds__(512) gemm_tile_kernel(TileArgs a) {
                 const int row = row0 + b * 16 + l15;
                 const int pos = e_pos[b];
                 const float ri = rownorm_rinv(q.rn, min(row, a.M - 1));  // deferred input norm (1 when the planes were normalised)
-                float ss = 0.f;
+                // whole-vector arithmetic on the f32x4 accumulators: hipcc pairs it into v_pk_mul / v_pk_fma (two lanes' worth
+                // of flops per instruction) -- this epilogue is VALU-bound (every wave of the chip is in it at once)
+                f32x4 ss4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float x = acc[j][b][r] * ri;
-                        acc[j][b][r] = x;
-                        ss += x * x;
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const f32x4 x = acc[j][b] * ri;
+                    acc[j][b] = x;
+                    ss4 += x * x;
+                }
+                float ss = (ss4[0] + ss4[1]) + (ss4[2] + ss4[3]);
                 ss += __shfl_xor(ss, 16);  // the four lane groups hold the other 96 features of this token
                 ss += __shfl_xor(ss, 32);
                 const float rinv = 1.0f / sqrtf(ss / 128.0f + q.eps);
+                const float osc = hh < nh ? q.q_scale : 1.0f;  // q leaves scaled; folded into the norm weight
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float4 w1 = *reinterpret_cast<const float4*>(w + j * 16 + grp * 4), w2 = *reinterpret_cast<const float4*>(w + 64 + j * 16 + grp * 4);
-                    const float w1a[4] = {w1.x, w1.y, w1.z, w1.w}, w2a[4] = {w2.x, w2.y, w2.z, w2.w};
-                    const float ca[4] = {cs[j].x, cs[j].y, cs[j].z, cs[j].w}, sa[4] = {sn[j].x, sn[j].y, sn[j].z, sn[j].w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float n1 = (acc[j][b][r] * rinv) * w1a[r], n2 = (acc[j + 4][b][r] * rinv) * w2a[r];
-                        acc[j][b][r] = n1 * ca[r] - n2 * sa[r];
-                        acc[j + 4][b][r] = n2 * ca[r] + n1 * sa[r];
-                    }
+                    const f32x4 w1 = __builtin_bit_cast(f32x4, *reinterpret_cast<const float4*>(w + j * 16 + grp * 4)) * (rinv * osc);
+                    const f32x4 w2 = __builtin_bit_cast(f32x4, *reinterpret_cast<const float4*>(w + 64 + j * 16 + grp * 4)) * (rinv * osc);
+                    const f32x4 c = __builtin_bit_cast(f32x4, cs[j]), sn_ = __builtin_bit_cast(f32x4, sn[j]);
+                    const f32x4 n1 = acc[j][b] * w1, n2 = acc[j + 4][b] * w2;
+                    acc[j][b] = n1 * c - n2 * sn_;
+                    acc[j + 4][b] = n2 * c + n1 * sn_;
                 }
                 if (row < a.M) {
                     if (hh < nh) {
                         float* qo = q.q_out + (size_t)row * (nh * 128) + (size_t)hh * 128 + grp * 4;
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
-                            *reinterpret_cast<float4*>(qo + j * 16) = make_float4(acc[j][b][0] * q.q_scale, acc[j][b][1] * q.q_scale,
-                                                                                 acc[j][b][2] * q.q_scale, acc[j][b][3] * q.q_scale);
+                            *reinterpret_cast<float4*>(qo + j * 16) = make_float4(acc[j][b][0], acc[j][b][1], acc[j][b][2], acc[j][b][3]);
                     } else {
                         _Float16* k = reinterpret_cast<_Float16*>(q.kv.k) + (size_t)(e_blk[b] * kvl + (hh - nh)) * kBlockTokens * 128;
 #pragma unroll
