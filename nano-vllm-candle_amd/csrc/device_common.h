@@ -39,6 +39,14 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 // rcp(inf) = 0, i.e. -0 for very negative gates; no NaN.  The fine-seam op keeps the division.
 __device__ __forceinline__ float silu_mul(float g, float u) { return (g * __builtin_amdgcn_rcpf(1.0f + __expf(-g))) * u; }
 
+// 16 bytes of a stream that THIS CU reads once per launch (a sequence's K/V in decode): non-temporal, so the lines do not
+// displace what other kernels re-read from L2 / Infinity Cache (`global_load_dwordx4 ... nt`; guide, nt-weights row)
+__device__ __forceinline__ uint4 ld_stream16(const void* p) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

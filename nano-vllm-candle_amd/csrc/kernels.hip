@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(512) lmhead_kernel(const uint16_t* __restrict_
         for (int a = 0; a < NT; ++a) {
             const int ntc = min(nt0 + a, ntiles - 1);
 #pragma unroll
-            for (int j = 0; j < SC; ++j) w[a][j] = wp[((size_t)ntc * KT + kt + j) * 64 + lane];
+            for (int j = 0; j < SC; ++j) w[a][j] = ld_stream16(wp + ((size_t)ntc * KT + kt + j) * 64 + lane);  // read once per step, by this CU only
         }
     };
     auto compute = [&](int k0, int buf, const uint4 (&w)[NT][SC]) {
@@ -1602,7 +1602,7 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
     const _Float16* vbase = reinterpret_cast<const _Float16*>(a.kv.v);
     // one 32-token KV tile (tokens tb..tb+31 of block blk): 2*DC K fragments + DT V fragments, 16 KiB in 1 KiB wave-loads
     auto load_tile_at = [&](int blk, int tb, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT]) {
-        auto ld = [&](const _Float16* p) -> uint4 { return *reinterpret_cast<const uint4*>(p); };
+        auto ld = [&](const _Float16* p) -> uint4 { return ld_stream16(p); };
         // packed K: the two 16-token tiles of this 32-token step are 2*DC contiguous 1 KiB fragments
         const _Float16* kb = kbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 4) * (DC * 512) + lane * 8;
 #pragma unroll
@@ -1629,11 +1629,11 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
         const _Float16* vb = real ? vbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 5) * (DT * 512) + lane * 8 : dummy;
 #pragma unroll
         for (int c = 0; c < DC; ++c) {
-            ka[c] = *reinterpret_cast<const uint4*>(kb + c * 512);
-            kb2[c] = *reinterpret_cast<const uint4*>(kb + (DC + c) * 512);
+            ka[c] = ld_stream16(kb + c * 512);
+            kb2[c] = ld_stream16(kb + (DC + c) * 512);
         }
 #pragma unroll
-        for (int d = 0; d < DT; ++d) vf[d] = *reinterpret_cast<const uint4*>(vb + d * 512);
+        for (int d = 0; d < DT; ++d) vf[d] = ld_stream16(vb + d * 512);
     };
     // decode register sets (QT == 1): two 32-token tiles (32 KiB) of this wave are in flight at any time
     uint4 kaA[DC], kbA[DC], vfA[DT], kaB[DC], kbB[DC], vfB[DT];
