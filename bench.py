@@ -401,10 +401,13 @@ def main():
     model.profile_kernel(None)
     # an event pair around nothing, recorded between busy kernels: what every bracket adds to a launch's duration
     # A bracket around a launch adds less than a whole empty bracket (the second event's processing overlaps the
-    # kernel's tail): against rocprofv3 --kernel-trace on two runs of this command the excess was 0.80-0.85 of it
-    # (29.34/5.29/24.84 us and 29.48/5.51/25.06 us: bracketed / empty / rocprof); 0.8 keeps the figure conservative.
+    # kernel's tail).  Calibration against rocprofv3 --kernel-trace of this command, compared on the SAME step window
+    # (round 1 compared a bracketed figure of the later, longer-context profile steps with rocprof's all-step average and
+    # took 0.8): bracketed 26.79 us on the profile steps (95.9 MB per launch), empty bracket 5.89 us, rocprof 22.70 us over
+    # all steps (87.1 MB) = 24.3 us scaled to the profile steps' bytes (7 us fixed + a part proportional to the bytes):
+    # excess 2.5 us = 0.42 of the empty bracket.  0.4 keeps the figure conservative (a slightly longer kernel).
     empty_ms, empty_n = kern.pop("empty")
-    bracket_us = 0.8 * empty_ms / max(empty_n, 1) * 1e3
+    bracket_us = 0.4 * empty_ms / max(empty_n, 1) * 1e3
     per_step = {k: ms / pass_steps for k, (ms, n) in kern.items()}
     kv_layer = model.kv_bytes_per_token // cfg.num_hidden_layers  # K+V bytes of one token in one layer (this rank)
     # dominant kernel = the class that moves the most algorithmic bytes per step (the path is HBM-bound); the
