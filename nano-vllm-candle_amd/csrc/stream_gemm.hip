@@ -328,7 +328,8 @@ static hipError_t stream_launch_t(const StreamShape& sh, const StreamArgs& a, co
     const size_t lds = (size_t)2 * (2 * 4 * KC) * 1024;
     const int waves = (w.N / 16 + NT - 1) / NT;
     dim3 grid((waves + 7) / 8, sh.ks);
-    if (w.bytes() >= ((size_t)80 << 20)) {  // big matrix: non-temporal weight stream
+    static const size_t nt_min_bytes = (size_t)(getenv("NVLLM_STREAM_NT_MB") ? atoi(getenv("NVLLM_STREAM_NT_MB")) : 80) << 20;  // A/B switch
+    if (w.bytes() >= nt_min_bytes) {  // big matrix: non-temporal weight stream
         static std::atomic<uint64_t> lds_set_nt{0};
         ensure_dyn_lds(reinterpret_cast<const void*>(gemm_stream_kernel<NT, SC, KC, EPI, true>), lds, lds_set_nt);
         gemm_stream_kernel<NT, SC, KC, EPI, true><<<grid, 512, lds, s>>>(a, w.data, w.N, w.K / 32, w.K / 32 / sh.ks);
