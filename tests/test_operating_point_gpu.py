@@ -318,3 +318,45 @@ def test_concurrent_contexts_on_one_gpu_stay_correct(pkg, oracle):
         check_rows(f"6 concurrent contexts, step {step}", res[0][step][0], res[0][step][1], rid, rlg)
         for s, t in zip(ref, rid):
             s.append(int(t))
+
+
+def test_concurrent_prompt_chunks_are_bit_equal_to_a_solo_run(pkg):
+    # the prompt-chunk kernels (tile GEMM ring, prefill attention ring, 16-row norm) under memory load: four contexts prefill
+    # the same 3320 rows at once, three times each; the kernels are deterministic, so every result must equal the solo
+    # run bit for bit -- an LDS-DMA stage read before it was published shows only under load (tools/dbg_conc_prefill.py)
+    cfg = pkg.Qwen3Config.qwen3_0_6b()
+    cfg.num_hidden_layers = 4
+    rng = np.random.default_rng(5)
+    prompts = [rng.integers(0, cfg.vocab_size, int(n)).tolist() for n in (61, 293, 510, 515, 130, 77, 402, 333, 256, 199, 64, 480)]
+    n = len(prompts)
+
+    def make(c):
+        m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, c)
+        m.kv_alloc(num_blocks=3 * n + 2, max_seqs=n, max_batched_tokens=4096)
+        return m
+
+    c0 = pkg.Context(0)
+    m0 = make(c0)
+    ref_ids, ref_lg = m0.step(list(range(n)), prompts, True, want_logits=True)
+    assert m0.counter("tile_gemm_launches") > 0
+    bad = []
+
+    def worker(i):
+        c = pkg.Context(0)
+        m = make(c)
+        for r in range(3):
+            m.kv_alloc(num_blocks=3 * n + 2, max_seqs=n, max_batched_tokens=4096)
+            ids, lg = m.step(list(range(n)), prompts, True, want_logits=True)
+            if not (np.array_equal(ids, ref_ids) and np.array_equal(lg, ref_lg)):
+                bad.append((i, r, float(np.abs(lg - ref_lg).max())))
+        m.close()
+        c.close()
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    m0.close()
+    c0.close()
+    assert not bad, bad
