@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--max-batched-tokens", type=int, default=4096,
                     help="rows per internal prefill chunk (SchedulerConfig.max_num_batched_tokens, scheduler.rs:10-56: default 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seqs", type=int, default=2, help="sequences of the batch the CPU baseline re-runs")
+    ap.add_argument("--cpu-seqs", type=int, default=12, help="sequences of the batch the CPU baseline re-runs (about 10-20 s of CPU work)")
     ap.add_argument("--profile-steps", type=int, default=8, help="extra steps for the per-kernel HIP-event pass")
     ap.add_argument("--parallel", default="dp", choices=["dp", "tp"],
                     help="N>1: dp = one TP=1 replica per GPU (weak scaling, no collective); tp = one TP=N group")
