@@ -63,6 +63,12 @@ def parse():
     ap.add_argument("--prefill-only", action="store_true",
                     help="time the prefill of the batch (cold call + warmed repeats) and stop: the MFMA-side profile run")
     ap.add_argument("--prefill-reps", type=int, default=3)
+    ap.add_argument("--profile-meta", action="store_true",
+                    help="add `all_decode_steps` to the line (tools/summarize_prof.py: bytes per launch averaged over EVERY decode step "
+                         "of the process, what a rocprofv3 --stats average covers); off by default: one byte count per kernel in the line")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B aid: nvllm_debug_set_option on the headline model before kv_alloc (repeatable)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="plain `python bench.py --gpus N`: overall limit of the rank processes")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only (no GPU): every rank joins the gloo group, rank 0 prints the max rank seen")
     return ap.parse_args()
@@ -183,28 +189,52 @@ def run_tp_extra(pkg, torch, dist, a, rank, world, local_rank):
     return res
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, timeout_s=1500.0):
     """Launcher for `python bench.py --gpus N` without torch.distributed.run: N child processes with
     RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment, started BEFORE anything in this process initialises
-    the GPU (no exec of a GPU-initialised process anywhere).  Rank 0's stdout (the one JSON line) is relayed;
-    the exit code is non-zero when any rank fails."""
+    the GPU (no exec of a GPU-initialised process anywhere).  Rank 0's stdout (the one JSON line) is relayed.
+    Every child is polled: as soon as one exits non-zero, or after timeout_s, the rest are terminated and the exit
+    code is 1 (a rank that dies before the rendezvous would otherwise leave its peers in gloo's 30-minute timeout)."""
     import socket
     import subprocess
+    import tempfile
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    # the listening socket stays open (SO_REUSEADDR) until the children are started, so nobody else is handed the port
+    sk = socket.socket()
+    sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    out0 = tempfile.TemporaryFile(mode="w+")
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if r == 0:
+            sk.close()  # rank 0 binds the port next; the others only connect to it
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.monotonic() + timeout_s
+    bad = []
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad or all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > deadline:
+            bad = [(r, "timeout") for r, rc in enumerate(rcs) if rc is None]
+            break
+        time.sleep(0.2)
+    for p in procs:  # a failed or late run: stop what is still alive (exact PIDs we started)
+        if p.poll() is None:
+            p.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    out0.seek(0)
+    sys.stdout.write(out0.read())
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
         print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
         return 1
@@ -251,7 +281,7 @@ def main():
     if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: this process becomes the launcher (it never imports torch or touches a
         # GPU) and starts one fresh rank process per GPU, exactly what torch.distributed.run would have started
-        sys.exit(spawn_ranks(a.gpus))
+        sys.exit(spawn_ranks(a.gpus, a.launch_timeout))
     if world != a.gpus:
         sys.exit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     import numpy as np
@@ -265,7 +295,9 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane (id exchange, barrier, max over ranks) on gloo; the data path is RCCL inside the library
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     if a.launch_check:
         t = torch.tensor([float(rank)], dtype=torch.float64)
         if dist is not None:
@@ -303,6 +335,9 @@ def main():
     tpw = world if use_tp else 1
     cfg = model_config(pkg, a.model)
     model = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=a.seed, ctx=ctx)
+    for opt in a.option:
+        name, _, val = opt.partition("=")
+        model.set_option(name, int(val or 1))
     prompts = make_prompts(cfg, a.batch, a.prompt_min, a.prompt_max, a.seed + (0 if use_tp else rank))
     total_steps = a.warmup + a.steps + a.profile_steps + 2
     max_len = max(len(p) for p in prompts) + total_steps
@@ -328,14 +363,24 @@ def main():
         torch.cuda.synchronize()
         tw.append(time.perf_counter() - tp0)
     prefill_s = min(tw)
-    mm_params = (model.weight_bytes * tpw) / 2
-    pf_tflops = 2.0 * mm_params * prefill_tokens / prefill_s / 1e12
-    # prefill is the MFMA-bound side: algorithmic flops = 2 * matmul params * tokens (attention excluded);
-    # the kernels issue 2x that on the MFMA pipe because activations are bf16 hi + lo
+    # prefill is the MFMA-bound side.  Algorithmic flops of what the kernels compute: the four layer projections on every
+    # prompt token, the LM head on the LAST row of every sequence only (compute_logits is needed for row len-1,
+    # llm_engine.rs:181-183; the reference runs it on all rows, qwen3.rs:548), attention reported as its own term.  The
+    # kernels issue 2x the projection flops on the MFMA pipe because activations are bf16 hi + lo.
+    layer_params = cfg.hidden_size * (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim \
+        + cfg.hidden_size * cfg.num_attention_heads * cfg.head_dim + 3 * cfg.hidden_size * cfg.intermediate_size
+    proj_flops = 2.0 * cfg.num_hidden_layers * layer_params * prefill_tokens
+    lm_flops = 2.0 * cfg.vocab_size * cfg.hidden_size * len(prompts)
+    attn_flops = 4.0 * cfg.num_attention_heads * cfg.head_dim * cfg.num_hidden_layers * sum(len(p) * (len(p) + 1) / 2 for p in prompts)
+    pf_tflops = (proj_flops + lm_flops) / prefill_s / 1e12
     prefill_info = {"tokens": prefill_tokens, "ms": prefill_s * 1e3, "ms_first_call": prefill_cold_s * 1e3,
                     "tokens_per_s": prefill_tokens / prefill_s, "algorithmic_tflops": pf_tflops,
+                    "algorithmic_flops": {"layer_projections": proj_flops, "lm_head_last_rows": lm_flops,
+                                          "attention_causal_not_in_frac": attn_flops},
                     "mfma_peak_tflops_bf16_dense": 2500.0 * tpw, "frac_of_mfma_peak": pf_tflops / (2500.0 * tpw),
-                    "note": "warmed (repeat of the same prefill); ms_first_call includes one-time setup"}
+                    "frac_of_mfma_peak_with_attention": (proj_flops + lm_flops + attn_flops) / prefill_s / 1e12 / (2500.0 * tpw),
+                    "note": "warmed (repeat of the same prefill); ms_first_call includes one-time setup; frac = (projections on "
+                            "all tokens + LM head on last rows) / time / dense bf16 peak"}
     if a.prefill_only:
         if rank == 0:
             print(json.dumps({"metric": "prefill tokens/sec", "value": prefill_tokens / prefill_s, "unit": "tokens/s",
@@ -423,10 +468,10 @@ def main():
         dom_name = "attn_paged_kernel<128, 1, 4, true>"
     elif dom == "lm_head":
         dom_bytes = float(lm_bytes)
-        dom_name = "gemm_kernel (LM head)"
+        dom_name = "lmhead_kernel"
     elif dom == "gemm":
         dom_bytes = float(model.weight_bytes - lm_bytes) / (4 * cfg.num_hidden_layers)
-        dom_name = "gemm_kernel (layer projections, mean of qkv/o/gate_up/down)"
+        dom_name = "layer projection GEMMs (mean of qkv / o_proj / gate_up / down launches)"
     else:
         dom_bytes = None
         dom_name = dom
@@ -442,8 +487,9 @@ def main():
     for pmc_path in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_fetch_size.json") and default_workload), reverse=True):
         pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_path))).get(dom_name)
         if pmc:
-            roof["traffic_from_profile"] = {"file": "profiles/" + pmc_path, "fetch_bytes_per_launch": pmc["fetch_bytes_per_launch"],
-                                            "algorithmic_bytes_per_launch": pmc["algorithmic_bytes_per_launch"]}
+            # the committed counter pass of this same command: only the RATIO is quoted here (its byte counts live in the file)
+            roof["traffic_from_profile"] = {"file": "profiles/" + pmc_path,
+                                            "hbm_fetch_over_algorithmic": pmc["fetch_bytes_per_launch"] / pmc["algorithmic_bytes_per_launch"]}
             break
     if dom_bytes is not None:
         roof["achieved"] = dom_bytes / (launch_us * 1e-6) / 1e9
@@ -463,14 +509,15 @@ def main():
                           "frac": step_gbs / HBM_PEAK_GBS, "bytes_per_step": bytes_total / a.steps,
                           "event_ms_per_step": ev_ms / a.steps},
         "kernel_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
+    }
+    if a.profile_meta:
         # for tools/summarize_prof.py: the attention kernel's algorithmic bytes per launch averaged over ALL decode steps of
         # this process (warm-up + timed + per-kernel pass) -- the launches a rocprofv3 --stats average covers
-        "all_decode_steps": {"steps": len(all_step_tokens), "attn_algorithmic_bytes_per_launch": float(np.mean(all_step_tokens)) * kv_layer if all_step_tokens else None,
-                             "weight_bytes": {"qkv": 2 * cfg.hidden_size * (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim // tpw,
-                                              "o_proj": 2 * cfg.hidden_size * cfg.num_attention_heads * cfg.head_dim // tpw,
-                                              "gate_up": 4 * cfg.hidden_size * cfg.intermediate_size // tpw,
-                                              "down": 2 * cfg.hidden_size * cfg.intermediate_size // tpw, "lm_head": lm_bytes}},
-    }
+        out["all_decode_steps"] = {"steps": len(all_step_tokens), "attn_algorithmic_bytes_per_launch": float(np.mean(all_step_tokens)) * kv_layer if all_step_tokens else None,
+                                   "weight_bytes": {"qkv": 2 * cfg.hidden_size * (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim // tpw,
+                                                    "o_proj": 2 * cfg.hidden_size * cfg.num_attention_heads * cfg.head_dim // tpw,
+                                                    "gate_up": 4 * cfg.hidden_size * cfg.intermediate_size // tpw,
+                                                    "down": 2 * cfg.hidden_size * cfg.intermediate_size // tpw, "lm_head": lm_bytes}}
     out["prefill"] = prefill_info
     if rank == 0 and world == 1 and not a.no_cpu_baseline:  # reported at N=1 only (driver contract)
         out["cpu_baseline"] = cpu_baseline(cfg, prompts, a.cpu_seqs, a.seed)

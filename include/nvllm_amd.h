@@ -94,6 +94,11 @@ int nvllm_model_load_tensor(nvllm_model* m, const char* hf_name, const void* hos
 /* Fill every tensor from the deterministic generator (oracle/synth.h documents the recipe) directly
  * in HBM -- bench / test input, identical values on every machine and every TP rank layout. */
 int nvllm_model_fill_synthetic(nvllm_model* m, uint64_t seed);
+/* The same with a choice of value statistics: profile 0 = the call above (256 distinct small values, norm weights near 1);
+ * profile 1 = "heavy": full bf16 mantissas over five octaves, norm weights in [2^-5, 2^5), q/k-norm weights in [2^-4, 2^4),
+ * four outlier hidden channels amplified x64 in embed_tokens / o_proj / down_proj (massive activations on the residual
+ * stream) -- the statistics real Qwen3 checkpoints have; parity stress input (tests/test_stress_gpu.py). */
+int nvllm_model_fill_synthetic_profile(nvllm_model* m, uint64_t seed, int profile);
 int nvllm_model_finalize(nvllm_model* m);
 /* bytes of weights this rank reads per decode step (layers + final norm + LM head; embedding excluded) */
 int64_t nvllm_model_weight_bytes(const nvllm_model* m);

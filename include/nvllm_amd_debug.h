@@ -33,7 +33,9 @@ int nvllm_profile_read(nvllm_model* m, double* total_ms, int64_t* launches);
 int nvllm_debug_set_option(nvllm_model* m, const char* name, int value);
 
 /* counters for tests: "oneshot_calls" = all-reduces run on the one-shot device path by this model's context;
- * "tile_gemm_launches" = projections run by the prefill tile GEMM */
+ * "tile_gemm_launches" = projections run by the prefill tile GEMM; "kv_f16_saturated" = elements of the K/V pool at the
+ * f16 clamp (every cache write saturates at +-65504; a scan of the pool, off the hot path); "kv_f16_absmax_bits" = the
+ * largest magnitude the pool holds, as f16 bits */
 int nvllm_debug_get_counter(nvllm_model* m, const char* name, int64_t* value);
 
 /* Diagnostic build only (make -C nano-vllm-candle_amd/csrc stamps -> libnvllm_amd_stamps.so, select it with NVLLM_LIB):
@@ -46,6 +48,11 @@ int nvllm_debug_stamps_read(nvllm_model* m, int launch, uint64_t* out, int64_t c
  * 1 residual; [rows, hidden] f32 of layer `layer`; rows = rows of the last step's last chunk */
 int nvllm_debug_layer_tap(nvllm_model* m, int layer, int what, float* out, int64_t capacity_floats);
 int nvllm_debug_enable_taps(nvllm_model* m, int enable);
+
+/* device generator access for tests, any profile (nvllm_op_synth_bf16 is profile 0): kind 0 matrix / 1 norm / 2 q,k-norm;
+ * axis 0 none / 1 hidden channel = idx mod cols / 2 = idx / cols; outlier channels derive from (seed, hidden_size) */
+int nvllm_debug_synth_bf16_spec(nvllm_ctx* ctx, const char* name, uint64_t seed, int kind, int profile, int axis, int64_t cols,
+                                int hidden_size, int64_t first, int64_t count, uint16_t* host_out);
 
 /* tuning aid: time one decomposition (n-tiles per wave, waves per workgroup, K splits; 0 = planner's choice)
  * of y[M,N] = x[M,K].W^T on synthetic operands; returns microseconds per launch */

@@ -55,6 +55,7 @@ _SIGS = {
     "nvllm_model_destroy": (C.c_int, [_vp]),
     "nvllm_model_load_tensor": (C.c_int, [_vp, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "nvllm_model_fill_synthetic": (C.c_int, [_vp, C.c_uint64]),
+    "nvllm_model_fill_synthetic_profile": (C.c_int, [_vp, C.c_uint64, C.c_int]),
     "nvllm_model_finalize": (C.c_int, [_vp]),
     "nvllm_model_weight_bytes": (C.c_int64, [_vp]),
     "nvllm_tp_shard": (C.c_int, [C.POINTER(Qwen3ConfigC), C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int64)]),
@@ -88,6 +89,8 @@ _SIGS = {
     "nvllm_op_argmax": (C.c_int, [_vp, _fp, C.c_int, C.c_int, _fp]),
     "nvllm_op_allreduce": (C.c_int, [_vp, _fp, C.c_int64]),
     "nvllm_op_synth_bf16": (C.c_int, [_vp, C.c_char_p, C.c_uint64, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_uint16)]),
+    "nvllm_debug_synth_bf16_spec": (C.c_int, [_vp, C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int64,
+                                              C.POINTER(C.c_uint16)]),
     "nvllm_debug_gemm_bench": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "nvllm_debug_gemm_bench2": (C.c_int, [_vp] + [C.c_int] * 10 + [C.POINTER(C.c_float)]),
     "nvllm_debug_get_counter": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),

@@ -61,6 +61,7 @@ struct nvllm_ctx {
     uint32_t* os_flag = nullptr;  // [2][tp]
     unsigned* os_done = nullptr;  // push kernel's workgroup counter
     int* os_err = nullptr;        // set by a wait that timed out
+    int* os_agree = nullptr;      // [tp] error words gathered at the end of a step: every rank takes the same decision
     size_t os_slot = 0;
     uint64_t os_calls = 0;
     OneShotPeers os_peers;
@@ -178,7 +179,8 @@ static void oneshot_free(nvllm_ctx* ctx) {
     if (ctx->os_flag) (void)hipFree(ctx->os_flag);
     if (ctx->os_done) (void)hipFree(ctx->os_done);
     if (ctx->os_err) (void)hipFree(ctx->os_err);
-    ctx->os_data = nullptr; ctx->os_flag = nullptr; ctx->os_done = nullptr; ctx->os_err = nullptr;
+    if (ctx->os_agree) (void)hipFree(ctx->os_agree);
+    ctx->os_data = nullptr; ctx->os_flag = nullptr; ctx->os_done = nullptr; ctx->os_err = nullptr; ctx->os_agree = nullptr;
     ctx->oneshot = false; ctx->os_slot = 0; ctx->os_peers = OneShotPeers();
 }
 
@@ -198,9 +200,10 @@ static int oneshot_setup(nvllm_ctx* ctx, size_t slot_floats) {
         return e;
     };
     bool ok = alloc((void**)&ctx->os_data, data_bytes) == hipSuccess && alloc((void**)&ctx->os_flag, std::max<size_t>(flag_bytes, 256)) == hipSuccess &&
-              hipMalloc((void**)&ctx->os_done, 256) == hipSuccess && hipMalloc((void**)&ctx->os_err, 256) == hipSuccess;
+              hipMalloc((void**)&ctx->os_done, 256) == hipSuccess && hipMalloc((void**)&ctx->os_err, 256) == hipSuccess &&
+              hipMalloc((void**)&ctx->os_agree, 256) == hipSuccess;
     if (ok) ok = hipMemset(ctx->os_flag, 0, std::max<size_t>(flag_bytes, 256)) == hipSuccess && hipMemset(ctx->os_done, 0, 256) == hipSuccess &&
-                 hipMemset(ctx->os_err, 0, 256) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+                 hipMemset(ctx->os_err, 0, 256) == hipSuccess && hipMemset(ctx->os_agree, 0, 256) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
     int all_ok = ok ? 1 : 0;
     if (ctx->loop) {
         LoopGroup& g = *ctx->loop;
@@ -457,7 +460,11 @@ struct nvllm_model {
     // consumer launch on MI355X (Qwen3-8B batch 64: 8.6 vs 6.4 ms/step; 32B TP=8 shard: 8.9 vs 6.5 ms) -- one workgroup
     // per n-group reads every slab behind an agent-scope release of all the others.  nvllm_debug_set_option turns it on.
     int opt_stream_combine = 0;
-    int opt_oneshot_allreduce = getenv("NVLLM_ONESHOT_AR") ? atoi(getenv("NVLLM_ONESHOT_AR")) : 0;  // TP decode: one-shot all-reduce (set before kv_alloc)
+    int opt_oneshot_allreduce = 0;  // TP decode: one-shot all-reduce instead of the communicator's (set before kv_alloc; opt-in)
+    int opt_oneshot_skip_push = 0;     // test hook: this rank "forgets" its next N pushes (the give-up path of its peers' waits)
+    int opt_oneshot_spins = 20000000;  // bound of the one-shot wait kernel's poll (~ seconds): a missing peer is an error code
+    int opt_no_fused = 0, opt_no_xpack = 0, opt_no_rowpar = 0;  // A/B switches (nvllm_debug_set_option): force the generic paths
+    int opt_no_attn_prologue = 0;  // A/B: decode q/k-norm + RoPE + KV write in their own row kernel, not in the attention prologue
     int opt_tile_fuse_qk = 1;    // QKV tile GEMM with the q/k-norm + RoPE + KV-write epilogue (head_dim 128, 256-wide blocks)
     int opt_tile_min_wgs = 192;  // prefill tile GEMM: smallest grid it is used for (256-row tiles need rows to fill 256 CUs)
     unsigned* tickets = nullptr;             // arrival counters of the streaming GEMM's in-launch combine (zero between launches)
@@ -643,6 +650,7 @@ struct Target {
     int dst_row0 = 0;
     int ileave = -1;  // gate (0) / up (1): interleaved 16-row tiles
     int synth_kind = kSynthMatrix;
+    int synth_axis = kSynthAxisNone;  // where the hidden channel sits in the FULL tensor (heavy synthetic profile: outlier channels)
 };
 
 static bool resolve(nvllm_model* m, const char* name, Target& t) {
@@ -650,13 +658,13 @@ static bool resolve(nvllm_model* m, const char* name, Target& t) {
     const int rank = m->ctx->tp_rank;
     const int64_t H = m->H, hd = m->hd, nh = c.num_attention_heads, kv = c.num_key_value_heads, I = c.intermediate_size, V = c.vocab_size;
     if (!strcmp(name, "model.embed_tokens.weight")) {
-        t.kind = Target::BF16ROWS; t.b = m->embed; t.full_rows = V; t.full_cols = H; t.rows = V; t.cols = H; return true;
+        t.kind = Target::BF16ROWS; t.b = m->embed; t.full_rows = V; t.full_cols = H; t.rows = V; t.cols = H; t.synth_axis = kSynthAxisCol; return true;
     }
     if (!strcmp(name, "lm_head.weight")) {
         t.w = &m->lm_head; t.full_rows = V; t.full_cols = H; t.r0 = (int64_t)rank * m->V_l; t.rows = m->V_l; t.cols = H; return true;
     }
     if (!strcmp(name, "model.norm.weight")) {
-        t.kind = Target::F32VEC; t.f = m->norm; t.full_rows = 1; t.full_cols = H; t.rows = 1; t.cols = H; t.synth_kind = kSynthNorm; return true;
+        t.kind = Target::F32VEC; t.f = m->norm; t.full_rows = 1; t.full_cols = H; t.rows = 1; t.cols = H; t.synth_kind = kSynthNorm; t.synth_axis = kSynthAxisCol; return true;
     }
     int l = -1, off = 0;
     if (sscanf(name, "model.layers.%d.%n", &l, &off) != 1 || l < 0 || l >= m->L || off == 0) return false;
@@ -666,13 +674,14 @@ static bool resolve(nvllm_model* m, const char* name, Target& t) {
     if (!strcmp(s, "self_attn.q_proj.weight")) { t.w = &w.qkv; t.full_rows = nh * hd; t.full_cols = H; t.r0 = rank * qr; t.rows = qr; t.cols = H; t.dst_row0 = 0; return true; }
     if (!strcmp(s, "self_attn.k_proj.weight")) { t.w = &w.qkv; t.full_rows = kv * hd; t.full_cols = H; t.r0 = rank * kr; t.rows = kr; t.cols = H; t.dst_row0 = (int)qr; return true; }
     if (!strcmp(s, "self_attn.v_proj.weight")) { t.w = &w.qkv; t.full_rows = kv * hd; t.full_cols = H; t.r0 = rank * kr; t.rows = kr; t.cols = H; t.dst_row0 = (int)(qr + kr); return true; }
-    if (!strcmp(s, "self_attn.o_proj.weight")) { t.w = &w.o; t.full_rows = H; t.full_cols = nh * hd; t.c0 = rank * qr; t.rows = H; t.cols = qr; return true; }
+    if (!strcmp(s, "self_attn.o_proj.weight")) { t.w = &w.o; t.full_rows = H; t.full_cols = nh * hd; t.c0 = rank * qr; t.rows = H; t.cols = qr; t.synth_axis = kSynthAxisRow; return true; }
     if (!strcmp(s, "mlp.gate_proj.weight")) { t.w = &w.gu; t.full_rows = I; t.full_cols = H; t.r0 = (int64_t)rank * m->I_l; t.rows = m->I_l; t.cols = H; t.dst_row0 = 0; t.ileave = 0; return true; }
     if (!strcmp(s, "mlp.up_proj.weight")) { t.w = &w.gu; t.full_rows = I; t.full_cols = H; t.r0 = (int64_t)rank * m->I_l; t.rows = m->I_l; t.cols = H; t.dst_row0 = 0; t.ileave = 1; return true; }
-    if (!strcmp(s, "mlp.down_proj.weight")) { t.w = &w.down; t.full_rows = H; t.full_cols = I; t.c0 = (int64_t)rank * m->I_l; t.rows = H; t.cols = m->I_l; return true; }
+    if (!strcmp(s, "mlp.down_proj.weight")) { t.w = &w.down; t.full_rows = H; t.full_cols = I; t.c0 = (int64_t)rank * m->I_l; t.rows = H; t.cols = m->I_l; t.synth_axis = kSynthAxisRow; return true; }
     t.kind = Target::F32VEC; t.synth_kind = kSynthNorm; t.full_rows = 1; t.rows = 1;
-    if (!strcmp(s, "input_layernorm.weight")) { t.f = w.ln1; t.full_cols = t.cols = H; return true; }
-    if (!strcmp(s, "post_attention_layernorm.weight")) { t.f = w.ln2; t.full_cols = t.cols = H; return true; }
+    if (!strcmp(s, "input_layernorm.weight")) { t.f = w.ln1; t.full_cols = t.cols = H; t.synth_axis = kSynthAxisCol; return true; }
+    if (!strcmp(s, "post_attention_layernorm.weight")) { t.f = w.ln2; t.full_cols = t.cols = H; t.synth_axis = kSynthAxisCol; return true; }
+    t.synth_kind = kSynthQkNorm;
     if (!strcmp(s, "self_attn.q_norm.weight")) { t.f = w.qn; t.full_cols = t.cols = hd; return true; }
     if (!strcmp(s, "self_attn.k_norm.weight")) { t.f = w.kn; t.full_cols = t.cols = hd; return true; }
     return false;
@@ -731,17 +740,20 @@ extern "C" int nvllm_model_load_tensor(nvllm_model* m, const char* hf_name, cons
     return NVLLM_OK;
 }
 
-static int synth_one(nvllm_model* m, const char* name, uint64_t seed) {
+static int synth_one(nvllm_model* m, const char* name, uint64_t seed, int profile) {
     nvllm_ctx* ctx = m->ctx;
     Target t;
     if (!resolve(m, name, t)) return fail(ctx, NVLLM_EINVAL, "internal: bad tensor name %s", name);
-    const uint64_t nh = synth_hash_name(name, seed);
+    SynthSpec sp;
+    sp.name_hash = synth_hash_name(name, seed);
+    sp.kind = t.synth_kind; sp.profile = profile; sp.axis = t.synth_axis; sp.cols = t.full_cols;
+    synth_set_outliers(sp, seed, m->H);
     if (t.kind == Target::F32VEC) {
-        HIPCHK(ctx, launch_synth_rowmajor_f32(t.f, nh, t.synth_kind, 0, t.cols, ctx->stream));
+        HIPCHK(ctx, launch_synth_rowmajor_f32(t.f, sp, 0, t.cols, ctx->stream));
     } else if (t.kind == Target::BF16ROWS) {
-        HIPCHK(ctx, launch_synth_rowmajor_bf16(t.b, nh, kSynthMatrix, 0, t.rows * t.cols, ctx->stream));
+        HIPCHK(ctx, launch_synth_rowmajor_bf16(t.b, sp, 0, t.rows * t.cols, ctx->stream));
     } else {
-        HIPCHK(ctx, launch_synth_packed(*t.w, t.dst_row0, (int)t.rows, nh, t.r0, t.c0, t.full_cols, t.ileave, ctx->stream));
+        HIPCHK(ctx, launch_synth_packed(*t.w, t.dst_row0, (int)t.rows, sp, t.r0, t.c0, t.full_cols, t.ileave, ctx->stream));
     }
     m->loaded[name] = true;
     return NVLLM_OK;
@@ -771,23 +783,25 @@ extern "C" int nvllm_tp_shard(const nvllm_qwen3_config* cfg, int tp_size, int tp
     return NVLLM_OK;
 }
 
-extern "C" int nvllm_model_fill_synthetic(nvllm_model* m, uint64_t seed) {
+extern "C" int nvllm_model_fill_synthetic_profile(nvllm_model* m, uint64_t seed, int profile) {
     if (!m) return NVLLM_EINVAL;
+    if (profile != 0 && profile != 1) return fail(m->ctx, NVLLM_EINVAL, "synthetic profile %d unknown (0 benign, 1 heavy)", profile);
     HIPCHK(m->ctx, hipSetDevice(m->ctx->device));
-    int rc = synth_one(m, "model.embed_tokens.weight", seed);
-    if (!rc) rc = synth_one(m, "lm_head.weight", seed);
-    if (!rc) rc = synth_one(m, "model.norm.weight", seed);
+    int rc = synth_one(m, "model.embed_tokens.weight", seed, profile);
+    if (!rc) rc = synth_one(m, "lm_head.weight", seed, profile);
+    if (!rc) rc = synth_one(m, "model.norm.weight", seed, profile);
     char name[160];
     for (int l = 0; l < m->L && !rc; ++l)
         for (const char* s : kLayerTensors) {
             snprintf(name, sizeof name, "model.layers.%d.%s", l, s);
-            rc = synth_one(m, name, seed);
+            rc = synth_one(m, name, seed, profile);
             if (rc) break;
         }
     if (rc) return rc;
     HIPCHK(m->ctx, hipStreamSynchronize(m->ctx->stream));
     return NVLLM_OK;
 }
+extern "C" int nvllm_model_fill_synthetic(nvllm_model* m, uint64_t seed) { return nvllm_model_fill_synthetic_profile(m, seed, 0); }
 
 extern "C" int nvllm_model_finalize(nvllm_model* m) {
     if (!m) return NVLLM_EINVAL;
@@ -844,6 +858,8 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     if (m->opt_oneshot_allreduce && ctx->tp_size > 1 && !ctx->null_comm) {
         // collective: every rank of the group reaches this with the same option (slot = the largest fused decode message)
         (void)oneshot_setup(ctx, (size_t)kFusedMaxRows * m->H);
+    } else if (ctx->oneshot) {
+        oneshot_free(ctx);  // option switched off: back to the communicator's all-reduce (same decision on every rank)
     }
     const int by_pos = (m->cfg.max_position_embeddings + kBlockTokens - 1) / kBlockTokens;
     m->max_blocks = std::max(1, std::min(num_blocks, by_pos));
@@ -1004,9 +1020,10 @@ static int tp_reduce(nvllm_model* m, int rows, int ns, const float** in, int* n_
         // one-shot all-reduce (oneshot.hip): the consumer sums the tp slots like split-K slabs
         const int gen = (int)(ctx->os_calls & 1);
         const uint32_t seq = (uint32_t)(++ctx->os_calls);
-        HIPCHK(ctx, launch_oneshot_push(buf, (size_t)rows * m->H, ctx->os_peers, ctx->tp_size, ctx->tp_rank, ctx->os_slot, gen, seq, ctx->os_done, ctx->stream));
+        if (m->opt_oneshot_skip_push > 0) --m->opt_oneshot_skip_push;
+        else HIPCHK(ctx, launch_oneshot_push(buf, (size_t)rows * m->H, ctx->os_peers, ctx->tp_size, ctx->tp_rank, ctx->os_slot, gen, seq, ctx->os_done, ctx->stream));
         oneshot_loopback_order(ctx);
-        HIPCHK(ctx, launch_oneshot_wait(ctx->os_flag, ctx->tp_size, gen, seq, ctx->os_err, ctx->stream));
+        HIPCHK(ctx, launch_oneshot_wait(ctx->os_flag, ctx->tp_size, gen, seq, ctx->os_err, m->opt_oneshot_spins, ctx->stream));
         *in = ctx->os_data + (size_t)gen * ctx->tp_size * ctx->os_slot;
         *n_slabs = ctx->tp_size;
         *stride = (int64_t)ctx->os_slot;
@@ -1042,7 +1059,7 @@ struct FusedPlan {
 static bool fused_plan(const nvllm_model* m, int R, FusedPlan& p) {
     const int H = m->H, hd = m->hd, NQ = (m->nh_l + 2 * m->kv_l) * hd, KO = m->nh_l * hd, I2 = 2 * m->I_l;
     const bool tp = m->ctx->tp_size > 1;
-    if (R > kFusedMaxRows || m->taps || getenv("NVLLM_NO_FUSED")) return false;
+    if (R > kFusedMaxRows || m->taps || m->opt_no_fused) return false;
     auto fits = [&](int N, int K, int epi) {
         return m->opt_stream_combine && gemm_stream_ok(R, N, K, epi) && gemm_stream_slab_floats(R, N, K, epi) <= m->slab_floats;
     };
@@ -1071,7 +1088,7 @@ static bool fused_plan(const nvllm_model* m, int R, FusedPlan& p) {
     else if (fits(I2, H, 2)) p.gu = G_STREAM;
     else if (gemm_stream_splits(R, I2, H) > 0) return false;  // big gate/up: streaming slabs + SiLU launch beat the unsplit generic kernel
     else p.gu = G_GENERIC;  // generic kernel with the SwiGLU epilogue (no K split)
-    static const bool no_xpack = getenv("NVLLM_NO_XPACK") != nullptr;
+    const bool no_xpack = m->opt_no_xpack != 0;
     auto takes_packed = [&](int kind, int N, int K, int epi) { return kind == G_STREAM || (kind == G_ROW && gemm_rowdir_ok(N, K, epi, R)); };
     p.packed = !no_xpack && m->I_l % 32 == 0 && takes_packed(p.qkv, NQ, H, 2) && takes_packed(p.o, H, KO, tp ? 2 : 0) &&
                takes_packed(p.gu, I2, H, 1) && takes_packed(p.down, H, m->I_l, tp ? 2 : 0);
@@ -1146,9 +1163,10 @@ static int forward_chunk_fused(nvllm_model* m, const FusedPlan& fp, int R, int n
             // sum the tp slots like split-K slabs (every rank adds them in rank order: identical bits on all ranks)
             const int gen = (int)(ctx->os_calls & 1);
             const uint32_t seq = (uint32_t)(++ctx->os_calls);
-            HIPCHK(ctx, launch_oneshot_push(m->red, (size_t)R * H, ctx->os_peers, ctx->tp_size, ctx->tp_rank, ctx->os_slot, gen, seq, ctx->os_done, s));
+            if (m->opt_oneshot_skip_push > 0) --m->opt_oneshot_skip_push;
+            else HIPCHK(ctx, launch_oneshot_push(m->red, (size_t)R * H, ctx->os_peers, ctx->tp_size, ctx->tp_rank, ctx->os_slot, gen, seq, ctx->os_done, s));
             oneshot_loopback_order(ctx);
-            HIPCHK(ctx, launch_oneshot_wait(ctx->os_flag, ctx->tp_size, gen, seq, ctx->os_err, s));
+            HIPCHK(ctx, launch_oneshot_wait(ctx->os_flag, ctx->tp_size, gen, seq, ctx->os_err, m->opt_oneshot_spins, s));
             return prep(ctx->os_data + (size_t)gen * ctx->tp_size * ctx->os_slot, next_w, o_packed, ctx->tp_size, (int64_t)ctx->os_slot);
         }
         int rc = comm_allreduce_sum(ctx, m->red, (size_t)R * H);
@@ -1184,7 +1202,7 @@ static int forward_chunk_fused(nvllm_model* m, const FusedPlan& fp, int R, int n
         qa.q_scale = powf((float)hd, -0.5f) * 1.4426950408889634f;
         qa.q_out = m->qbuf; qa.rn = rn;
         qa.kv.k = m->kcache[l]; qa.kv.v = m->vcache[l]; qa.kv.kv_l = m->kv_l; qa.kv.hd = hd;
-        const bool fuse_qk = qt == 1 && n_tiles == R;
+        const bool fuse_qk = qt == 1 && n_tiles == R && !m->opt_no_attn_prologue;
         if (!fuse_qk) PROF(m, PROF_QK, launch_qk_norm_rope_kvwrite(qa, R, s));
         AttnArgs aa;
         aa.q = m->qbuf; aa.kv = qa.kv; aa.block_tables = m->d_block_tables; aa.max_blocks = m->max_blocks;
@@ -1264,7 +1282,7 @@ static int gemm_slabs(nvllm_model* m, const bf16_bits* xh, const bf16_bits* xl, 
     }
     if (x_packed) return fail(ctx, NVLLM_ESTATE, "packed activation planes reached a non-streaming GEMM");
     if (R <= kFusedMaxRows && gemm_rowpar_ok(w.N, w.K, 2, R) &&
-        (size_t)gemm_rowpar_splits(w.N, w.K, 2, R) * R * w.N <= m->slab_floats && !getenv("NVLLM_NO_ROWPAR")) {
+        (size_t)gemm_rowpar_splits(w.N, w.K, 2, R) * R * w.N <= m->slab_floats && !m->opt_no_rowpar) {
         RowParArgs ra;
         ra.xh = xh; ra.xl = xl; ra.ldx = ldx; ra.out = out; ra.M = R;
         PROF(m, PROF_GEMM, launch_gemm_rowpar(ra, w, 2, ctx->stream));
@@ -1293,7 +1311,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
     m->tap_rows = R;
     // big-model decode: when all four projections of a layer run the streaming GEMM, the activation planes between
     // the row kernels and the GEMMs stay in MFMA fragment order (xpack_off): x staging costs 3x per byte otherwise
-    static const bool no_xpack = getenv("NVLLM_NO_XPACK") != nullptr;
+    const bool no_xpack = m->opt_no_xpack != 0;
     const int packed = !no_xpack && !m->layers.empty() && gemm_streams(m, m->layers[0].qkv, R) && gemm_streams(m, m->layers[0].o, R) &&
                        gemm_streams(m, m->layers[0].gu, R) && gemm_streams(m, m->layers[0].down, R) && m->I_l % 32 == 0;
     // prompt chunks (MFMA-bound): projections whose grid fills the chip run the tile GEMM (tile_gemm.hip); it reads both
@@ -1382,7 +1400,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
             rg.xh = m->xh; rg.xl = m->xl; rg.ldx = H; rg.oh = m->xh2; rg.ol = m->xl2; rg.M = R;
             PROF(m, PROF_GEMM, launch_gemm_rowpar(rg, w.gu, 1, s));
         } else if (packed || (R <= kFusedMaxRows && gemm_rowpar_ok(2 * m->I_l, H, 2, R) &&
-                              (size_t)gemm_rowpar_splits(2 * m->I_l, H, 2, R) * R * 2 * m->I_l <= m->slab_floats && !getenv("NVLLM_NO_ROWPAR"))) {
+                              (size_t)gemm_rowpar_splits(2 * m->I_l, H, 2, R) * R * 2 * m->I_l <= m->slab_floats && !m->opt_no_rowpar)) {
             // big gate/up at few rows: stream it with K slices (f32 slabs of the INTERLEAVED gate/up rows),
             // then SiLU*mul on the summed slabs
             int gs = 1;
@@ -1458,16 +1476,28 @@ static void set_attn_split(nvllm_model* m, int n_seqs, int max_len) {
     m->attn_parts_max = (tiles + part - 1) / part;
 }
 
-// greedy ids (and optionally logits) of `n` last rows to the host; handles the vocab-parallel case
-// a one-shot all-reduce whose wait timed out (a peer never raised its flag) has left wrong sums: report it
+// A one-shot all-reduce whose wait timed out (a peer never raised its flag) has left wrong sums.  The error must not stay
+// per-rank: a rank that returned early would leave its peers in the collectives that follow (the (max, index) gather of
+// this very step).  So every rank contributes its error word to one small all-gather, all of them take the same
+// decision, and after an error all of them leave the one-shot path (the context falls back to the communicator's
+// all-reduce until the next kv_alloc sets the buffers up afresh).  A peer that is DEAD still hangs the communicator's own
+// collectives -- that is RCCL's failure model, not this protocol's.
 static int oneshot_check(nvllm_ctx* ctx) {
     if (!ctx->oneshot) return NVLLM_OK;
-    int e = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&e, ctx->os_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    const int tp = ctx->tp_size;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->os_agree + ctx->tp_rank, ctx->os_err, 4, hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = comm_allgather(ctx, ctx->os_agree + ctx->tp_rank, ctx->os_agree, 4);
+    if (rc) return rc;
+    int e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(e, ctx->os_agree, (size_t)tp * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (e) {
+    int bad = -1;
+    for (int r = 0; r < tp; ++r) if (e[r]) bad = r;
+    if (bad >= 0) {
         (void)hipMemsetAsync(ctx->os_err, 0, 4, ctx->stream);
-        return fail(ctx, NVLLM_ERCCL, "one-shot all-reduce: a peer's flag never arrived (timed out); this step's results are invalid");
+        ctx->oneshot = false;  // every rank reaches this line in the same step: the group leaves the device path together
+        return fail(ctx, NVLLM_ERCCL, "one-shot all-reduce: a peer's flag never arrived at rank %d (bounded wait gave up); this step's results are "
+                                      "invalid and the group is back on the communicator's all-reduce", bad);
     }
     return NVLLM_OK;
 }
@@ -1543,18 +1573,13 @@ static int upload_chunk(nvllm_model* m, const RowPlan& p, int r0, int R, int t0,
     memcpy(h_slot, p.slot.data() + r0, (size_t)R * 4);
     for (int i = 0; i < T; ++i) { h_t0[i] = p.tile_row0[t0 + i] - r0; h_tn[i] = p.tile_nrows[t0 + i]; h_ts[i] = p.tile_slot[t0 + i]; }
     for (size_t i = 0; i < last_local.size(); ++i) h_last[i] = last_local[i];
-    // attention load balance: q-tiles ordered by context length, longest first (stable for ties)
+    // attention load balance: q-tiles ordered by context length, longest first (stable for ties); an empty padding tile
+    // (prefill groups of four) has no last row: it sorts as -1, behind every real tile
     int* h_ord = h_last + m->max_seqs;
-    {
-        std::vector<int> ord(T);
-        for (int i = 0; i < T; ++i) ord[i] = i;
-        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) {
-            return p.pos[p.tile_row0[t0 + x] + p.tile_nrows[t0 + x] - 1] > p.pos[p.tile_row0[t0 + y] + p.tile_nrows[t0 + y] - 1];
-        });
-        for (int i = 0; i < T; ++i) h_ord[i] = ord[i];
-    }
     int* h_tl = h_ord + T;  // position of each tile's last row (-1: padding tile)
     for (int i = 0; i < T; ++i) h_tl[i] = p.tile_nrows[t0 + i] > 0 ? p.pos[p.tile_row0[t0 + i] + p.tile_nrows[t0 + i] - 1] : -1;
+    for (int i = 0; i < T; ++i) h_ord[i] = i;
+    std::stable_sort(h_ord, h_ord + T, [&](int x, int y) { return h_tl[x] > h_tl[y]; });
     HIPCHK(ctx, hipMemcpyAsync(m->d_ids, h_ids, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(m->d_pos, h_pos, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(m->d_slot, h_slot, (size_t)R * 4, hipMemcpyHostToDevice, s));
@@ -1834,6 +1859,12 @@ extern "C" int nvllm_debug_set_option(nvllm_model* m, const char* name, int valu
     if (!m || !name) return NVLLM_EINVAL;
     if (!strcmp(name, "stream_combine")) { m->opt_stream_combine = value; return NVLLM_OK; }
     if (!strcmp(name, "oneshot_allreduce")) { m->opt_oneshot_allreduce = value; return NVLLM_OK; }  // takes effect at the next kv_alloc
+    if (!strcmp(name, "oneshot_spins")) { m->opt_oneshot_spins = std::max(1, value); return NVLLM_OK; }
+    if (!strcmp(name, "oneshot_skip_push")) { m->opt_oneshot_skip_push = std::max(0, value); return NVLLM_OK; }  // test hook
+    if (!strcmp(name, "no_fused")) { m->opt_no_fused = value; return NVLLM_OK; }    // decode through the generic path
+    if (!strcmp(name, "no_xpack")) { m->opt_no_xpack = value; return NVLLM_OK; }    // row-major activation planes
+    if (!strcmp(name, "no_rowpar")) { m->opt_no_rowpar = value; return NVLLM_OK; }  // generic path: no whole-K row-parallel GEMMs
+    if (!strcmp(name, "no_attn_prologue")) { m->opt_no_attn_prologue = value; return NVLLM_OK; }
     if (!strcmp(name, "tile_fuse_qk")) { m->opt_tile_fuse_qk = value; return NVLLM_OK; }
     if (!strcmp(name, "tile_min_wgs")) { m->opt_tile_min_wgs = value; return NVLLM_OK; }  // <= 0: never use the tile GEMM
     return fail(m->ctx, NVLLM_EINVAL, "unknown option '%s'", name);
@@ -1845,6 +1876,28 @@ extern "C" int nvllm_debug_get_counter(nvllm_model* m, const char* name, int64_t
     if (!m || !name || !value) return NVLLM_EINVAL;
     if (!strcmp(name, "oneshot_calls")) { *value = (int64_t)m->ctx->os_calls; return NVLLM_OK; }
     if (!strcmp(name, "tile_gemm_launches")) { *value = m->tile_launches; return NVLLM_OK; }
+    if (!strcmp(name, "kv_f16_saturated") || !strcmp(name, "kv_f16_absmax_bits")) {
+        // scan of the whole K/V pool (debug, off the hot path): elements the f16_sat clamp of a cache write produced, and the
+        // largest magnitude stored (f16 bits; 0x7BFF = 65504 is the clamp)
+        if (m->kcache.empty()) return fail(m->ctx, NVLLM_ESTATE, "kv_alloc first");
+        nvllm_ctx* ctx = m->ctx;
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        unsigned long long* d = nullptr;
+        HIPCHK(ctx, hipMalloc((void**)&d, 16));
+        hipError_t e = hipMemsetAsync(d, 0, 16, ctx->stream);
+        const int64_t per_layer = (int64_t)m->num_blocks * m->kv_l * kBlockTokens * m->hd;
+        for (int l = 0; l < m->L && e == hipSuccess; ++l) {
+            e = launch_f16_scan(m->kcache[l], per_layer, d, reinterpret_cast<unsigned*>(d + 1), ctx->stream);
+            if (e == hipSuccess) e = launch_f16_scan(m->vcache[l], per_layer, d, reinterpret_cast<unsigned*>(d + 1), ctx->stream);
+        }
+        unsigned long long h[2] = {0, 0};
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d);
+        HIPCHK(ctx, e);
+        *value = !strcmp(name, "kv_f16_saturated") ? (int64_t)h[0] : (int64_t)(h[1] & 0xFFFFu);
+        return NVLLM_OK;
+    }
     return fail(m->ctx, NVLLM_EINVAL, "unknown counter '%s'", name);
 }
 
@@ -2105,7 +2158,24 @@ extern "C" int nvllm_op_synth_bf16(nvllm_ctx* ctx, const char* name, uint64_t se
     TmpBufs t;
     bf16_bits* d;
     HIPCHK(ctx, t.get(&d, (size_t)count));
-    HIPCHK(ctx, launch_synth_rowmajor_bf16(d, synth_hash_name(name, seed), kind, first, count, ctx->stream));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(d, synth_plain(synth_hash_name(name, seed), kind), first, count, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(host_out, d, (size_t)count * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return NVLLM_OK;
+}
+
+// the same for any generator profile (debug header): axis / cols / hidden_size say where an element's hidden channel sits
+extern "C" int nvllm_debug_synth_bf16_spec(nvllm_ctx* ctx, const char* name, uint64_t seed, int kind, int profile, int axis, int64_t cols,
+                                           int hidden_size, int64_t first, int64_t count, uint16_t* host_out) {
+    if (!ctx || !name || !host_out || count < 1 || cols < 1 || hidden_size < 1) return fail(ctx, NVLLM_EINVAL, "bad synth arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    TmpBufs t;
+    bf16_bits* d;
+    HIPCHK(ctx, t.get(&d, (size_t)count));
+    SynthSpec sp;
+    sp.name_hash = synth_hash_name(name, seed); sp.kind = kind; sp.profile = profile; sp.axis = axis; sp.cols = cols;
+    synth_set_outliers(sp, seed, hidden_size);
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(d, sp, first, count, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(host_out, d, (size_t)count * 2, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return NVLLM_OK;
@@ -2129,9 +2199,9 @@ extern "C" int nvllm_debug_gemm_bench(nvllm_ctx* ctx, int M, int N, int K, int n
     HIPCHK(ctx, t.get(&w.data, (size_t)N * K / 8));
     HIPCHK(ctx, t.get(&xh, (size_t)M * K)); HIPCHK(ctx, t.get(&xl, (size_t)M * K));
     HIPCHK(ctx, t.get(&out, (size_t)p.n_split * M * N));
-    HIPCHK(ctx, launch_synth_packed(w, 0, N, 12345, 0, 0, K, -1, s));
-    HIPCHK(ctx, launch_synth_rowmajor_bf16(xh, 777, kSynthMatrix, 0, (int64_t)M * K, s));
-    HIPCHK(ctx, launch_synth_rowmajor_bf16(xl, 778, kSynthMatrix, 0, (int64_t)M * K, s));
+    HIPCHK(ctx, launch_synth_packed(w, 0, N, synth_plain(12345, kSynthMatrix), 0, 0, K, -1, s));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(xh, synth_plain(777, kSynthMatrix), 0, (int64_t)M * K, s));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(xl, synth_plain(778, kSynthMatrix), 0, (int64_t)M * K, s));
     for (int i = 0; i < 3; ++i) HIPCHK(ctx, launch_gemm(p, xh, xl, K, w, out, M, s));
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
     for (int i = 0; i < iters; ++i) HIPCHK(ctx, launch_gemm(p, xh, xl, K, w, out, M, s));
@@ -2162,9 +2232,9 @@ extern "C" int nvllm_debug_gemm_tile_check(nvllm_ctx* ctx, int M, int N, int K, 
     HIPCHK(ctx, t.get(&ah0, Mp * No)); HIPCHK(ctx, t.get(&al0, Mp * No)); HIPCHK(ctx, t.get(&ah1, Mp * No)); HIPCHK(ctx, t.get(&al1, Mp * No));
     const int ks = mode == 0 ? std::max(1, gemm_tile_splits(M, N, K, 1, 4)) : 1;  // narrow outputs: the tile kernel splits K
     HIPCHK(ctx, t.get(&o0, (size_t)M * N)); HIPCHK(ctx, t.get(&o1, (size_t)ks * M * N));
-    HIPCHK(ctx, launch_synth_packed(w, 0, N, 4321, 0, 0, K, -1, s));
-    HIPCHK(ctx, launch_synth_rowmajor_bf16(xh, 777, kSynthMatrix, 0, (int64_t)M * K, s));
-    HIPCHK(ctx, launch_synth_rowmajor_bf16(xl, 778, kSynthMatrix, 0, (int64_t)M * K, s));
+    HIPCHK(ctx, launch_synth_packed(w, 0, N, synth_plain(4321, kSynthMatrix), 0, 0, K, -1, s));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(xh, synth_plain(777, kSynthMatrix), 0, (int64_t)M * K, s));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(xl, synth_plain(778, kSynthMatrix), 0, (int64_t)M * K, s));
     HIPCHK(ctx, launch_xpack_plane(xh, ph, M, K, s));
     HIPCHK(ctx, launch_xpack_plane(xl, pl, M, K, s));
     HIPCHK(ctx, hipMemsetAsync(ah1, 0, Mp * No * 2, s)); HIPCHK(ctx, hipMemsetAsync(al1, 0, Mp * No * 2, s));
@@ -2225,10 +2295,7 @@ extern "C" int nvllm_debug_gemm_tile_check(nvllm_ctx* ctx, int M, int N, int K, 
 // sequence; part_tokens 0 = no split.  Returns microseconds per launch (attention + combine).
 extern "C" int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int hd, const int32_t* ctx_lens,
                                       int part_tokens, int iters, float* us_per_call) {
-    // NVLLM_ATTN_ROT = number of distinct cache copies cycled through (default 8: every launch reads cold HBM,
-    // like the model's per-layer caches); 1 = same buffers every launch (Infinity-Cache warm)
-    const char* rot_env = getenv("NVLLM_ATTN_ROT");
-    const int nrot = rot_env ? std::max(1, atoi(rot_env)) : 8;
+    const int nrot = 8;  // distinct cache copies cycled through: every launch reads cold HBM, like the model's per-layer caches
     if (!ctx || !ctx_lens || !us_per_call || B < 1 || iters < 1 || (hd != 64 && hd != 128) || nh % kv)
         return fail(ctx, NVLLM_EINVAL, "bad attn_bench arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -2249,8 +2316,8 @@ extern "C" int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int
     std::vector<f16_bits*> rk(nrot), rv(nrot);
     for (int r = 0; r < nrot; ++r) {
         HIPCHK(ctx, t.get(&rk[r], cache_elems)); HIPCHK(ctx, t.get(&rv[r], cache_elems));
-        HIPCHK(ctx, launch_synth_rowmajor_bf16(rk[r], 1 + r, kSynthMatrix, 0, (int64_t)cache_elems, s));
-        HIPCHK(ctx, launch_synth_rowmajor_bf16(rv[r], 100 + r, kSynthMatrix, 0, (int64_t)cache_elems, s));
+        HIPCHK(ctx, launch_synth_rowmajor_bf16(rk[r], synth_plain(1 + r, kSynthMatrix), 0, (int64_t)cache_elems, s));
+        HIPCHK(ctx, launch_synth_rowmajor_bf16(rv[r], synth_plain(100 + r, kSynthMatrix), 0, (int64_t)cache_elems, s));
     }
     kvl.k = rk[0]; kvl.v = rv[0];
     HIPCHK(ctx, t.get(&q, (size_t)B * nh * hd)); HIPCHK(ctx, t.get(&oh, (size_t)B * nh * hd)); HIPCHK(ctx, t.get(&ol, (size_t)B * nh * hd));
@@ -2258,7 +2325,7 @@ extern "C" int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int
     HIPCHK(ctx, t.get(&dbt, hbt.size())); HIPCHK(ctx, t.get(&dpos, B)); HIPCHK(ctx, t.get(&dslot, B));
     HIPCHK(ctx, t.get(&dt0, B)); HIPCHK(ctx, t.get(&dtn, B)); HIPCHK(ctx, t.get(&dts, B));
     // bf16-valued synthetic bits reinterpreted as f16 are small finite numbers: fine for timing
-    HIPCHK(ctx, launch_synth_rowmajor_f32(q, 3, kSynthMatrix, 0, (int64_t)B * nh * hd, s));
+    HIPCHK(ctx, launch_synth_rowmajor_f32(q, synth_plain(3, kSynthMatrix), 0, (int64_t)B * nh * hd, s));
     HIPCHK(ctx, hipMemcpyAsync(dbt, hbt.data(), hbt.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(dpos, hpos.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(dslot, hslot.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
@@ -2275,29 +2342,6 @@ extern "C" int nvllm_debug_attn_bench(nvllm_ctx* ctx, int B, int nh, int kv, int
         if (parts_max > kAttnMaxParts) return fail(ctx, NVLLM_EINVAL, "too many parts");
     }
     for (int i = 0; i < 3; ++i) HIPCHK(ctx, launch_attn_paged(a, B, 1, B, parts_max, s));
-    if (getenv("NVLLM_ATTN_PF")) {
-        // experiment: warm the next launch's K/V with the cache-warmer kernel first, time the attention alone
-        PrefetchRange* dr; unsigned* sink;
-        HIPCHK(ctx, t.get(&dr, (size_t)2 * nrot)); HIPCHK(ctx, t.get(&sink, 1));
-        std::vector<PrefetchRange> hr;
-        for (int r = 0; r < nrot; ++r) { hr.push_back({rk[r], cache_elems * 2}); hr.push_back({rv[r], cache_elems * 2}); }
-        HIPCHK(ctx, hipMemcpyAsync(dr, hr.data(), hr.size() * sizeof(PrefetchRange), hipMemcpyHostToDevice, s));
-        std::vector<hipEvent_t> evs(2 * iters);
-        for (auto& e : evs) HIPCHK(ctx, hipEventCreate(&e));
-        for (int i = 0; i < iters; ++i) {
-            a.kv.k = rk[i % nrot]; a.kv.v = rv[i % nrot];
-            HIPCHK(ctx, launch_prefetch_ranges(dr + 2 * (i % nrot), 2, sink, atoi(getenv("NVLLM_ATTN_PF")), s));
-            HIPCHK(ctx, hipEventRecord(evs[2 * i], s));
-            HIPCHK(ctx, launch_attn_paged(a, B, 1, B, parts_max, s));
-            HIPCHK(ctx, hipEventRecord(evs[2 * i + 1], s));
-        }
-        HIPCHK(ctx, hipStreamSynchronize(s));
-        double tot = 0;
-        for (int i = 0; i < iters; ++i) { float ms = 0; HIPCHK(ctx, hipEventElapsedTime(&ms, evs[2 * i], evs[2 * i + 1])); tot += ms; }
-        for (auto& e : evs) (void)hipEventDestroy(e);
-        *us_per_call = (float)(tot * 1e3 / iters);
-        return NVLLM_OK;
-    }
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s));
     for (int i = 0; i < iters; ++i) {
         a.kv.k = rk[i % nrot]; a.kv.v = rv[i % nrot];
@@ -2333,7 +2377,6 @@ extern "C" int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int 
     hipStream_t s = ctx->stream;
     GemmPlan p = mode == 2 ? plan_gemm_swiglu(M, N, K) : plan_gemm(M, N, K, 64);
     if (mt > 0) { p.mt = mt; p.kc = mt == 8 ? 2 : 4; }
-    if (getenv("NVLLM_GEMM_KC")) p.kc = atoi(getenv("NVLLM_GEMM_KC"));
     if (nt > 0) p.nt = nt;
     if (nw > 0) p.nw = nw;
     set_split(p, K / 32, n_split > 0 ? n_split : p.n_split);
@@ -2342,14 +2385,14 @@ extern "C" int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int 
     for (int r = 0; r < rot; ++r) {
         ws[r].N = N; ws[r].K = K;
         HIPCHK(ctx, t.get(&ws[r].data, (size_t)N * K / 8));
-        HIPCHK(ctx, launch_synth_packed(ws[r], 0, N, 12345 + r, 0, 0, K, -1, s));
+        HIPCHK(ctx, launch_synth_packed(ws[r], 0, N, synth_plain(12345 + r, kSynthMatrix), 0, 0, K, -1, s));
     }
     bf16_bits *xh, *xl, *ah, *al; float* out;
     HIPCHK(ctx, t.get(&xh, (size_t)M * K)); HIPCHK(ctx, t.get(&xl, (size_t)M * K));
     HIPCHK(ctx, t.get(&ah, (size_t)M * N)); HIPCHK(ctx, t.get(&al, (size_t)M * N));
     HIPCHK(ctx, t.get(&out, (size_t)p.n_split * M * N));
-    HIPCHK(ctx, launch_synth_rowmajor_bf16(xh, 777, kSynthMatrix, 0, (int64_t)M * K, s));
-    HIPCHK(ctx, launch_synth_rowmajor_bf16(xl, 778, kSynthMatrix, 0, (int64_t)M * K, s));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(xh, synth_plain(777, kSynthMatrix), 0, (int64_t)M * K, s));
+    HIPCHK(ctx, launch_synth_rowmajor_bf16(xl, synth_plain(778, kSynthMatrix), 0, (int64_t)M * K, s));
     // modes 10/11/12: the row-parallel decode kernel with epilogue 0/1/2 (planner shapes; mt/nt/nw/n_split ignored)
     float *resid = nullptr, *nextw = nullptr, *ssq = nullptr, *ssq_in = nullptr;
     if (mode == 22 || mode == 23) {

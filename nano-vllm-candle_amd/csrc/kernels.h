@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "synth_device.h"
+
 namespace nvllm {
 
 typedef uint16_t bf16_bits;  // raw bf16 storage
@@ -24,15 +26,17 @@ struct PackedW {
 // ileave: -1 = rows land at row0.. ; 0/1 = gate(0)/up(1) rows interleaved in 16-row tiles (SwiGLU epilogue layout)
 hipError_t launch_pack_rows(const PackedW& dst, int row0, int rows, const bf16_bits* src, int64_t ld, int ileave,
                             hipStream_t s);
-// generate rows [row0,row0+rows) of dst from the synthetic tensor `name_hash`: logical element
+// generate rows [row0,row0+rows) of dst from the synthetic tensor `spec` (synth_device.h): logical element
 // (r, k) of the destination = source element (src_row0 + r, src_col0 + k) of a [*, src_ld] tensor
-hipError_t launch_synth_packed(const PackedW& dst, int row0, int rows, uint64_t name_hash, int64_t src_row0,
+hipError_t launch_synth_packed(const PackedW& dst, int row0, int rows, const SynthSpec& spec, int64_t src_row0,
                                int64_t src_col0, int64_t src_ld, int ileave, hipStream_t s);
 // row-major synthetic fill: dst bf16 [count] = elements [first, first+count)
-hipError_t launch_synth_rowmajor_bf16(bf16_bits* dst, uint64_t name_hash, int kind, int64_t first, int64_t count,
-                                      hipStream_t s);
-hipError_t launch_synth_rowmajor_f32(float* dst, uint64_t name_hash, int kind, int64_t first, int64_t count,
-                                     hipStream_t s);
+hipError_t launch_synth_rowmajor_bf16(bf16_bits* dst, const SynthSpec& spec, int64_t first, int64_t count, hipStream_t s);
+hipError_t launch_synth_rowmajor_f32(float* dst, const SynthSpec& spec, int64_t first, int64_t count, hipStream_t s);
+
+// debug scan of an f16 buffer (n % 8 == 0): *sat += elements at or above the f16_sat clamp (|x| >= 65504), *absmax_bits =
+// max(*absmax_bits, largest magnitude as f16 bits)
+hipError_t launch_f16_scan(const f16_bits* data, int64_t n, unsigned long long* sat, unsigned* absmax_bits, hipStream_t s);
 
 // ---- conversions ---------------------------------------------------------------------------------
 hipError_t launch_f32_to_bf16(const float* src, bf16_bits* dst, int64_t n, hipStream_t s);
@@ -201,7 +205,8 @@ struct OneShotPeers {
 };
 hipError_t launch_oneshot_push(const float* src, size_t n, const OneShotPeers& p, int tp, int rank, size_t slot_floats, int gen,
                                uint32_t seq, unsigned* done, hipStream_t s);
-hipError_t launch_oneshot_wait(const uint32_t* flags, int tp, int gen, uint32_t seq, int* err, hipStream_t s);
+// max_spins bounds the poll (each spin sleeps ~64 cycles): a flag that never arrives sets *err instead of hanging the stream
+hipError_t launch_oneshot_wait(const uint32_t* flags, int tp, int gen, uint32_t seq, int* err, long long max_spins, hipStream_t s);
 
 // ---- paged attention (prefill tiles and decode rows alike) ----------------------------------------
 struct AttnArgs {

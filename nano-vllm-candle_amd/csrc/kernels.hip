@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(uint4* __restrict__ dst,
 }
 
 __global__ void __launch_bounds__(256) synth_packed_kernel(uint4* __restrict__ dst, int KT, int row0, int rows,
-                                                           uint64_t name_hash, int64_t src_row0, int64_t src_col0,
+                                                           SynthSpec spec, int64_t src_row0, int64_t src_col0,
                                                            int64_t src_ld, int ileave) {
     const int64_t chunks_per_row = (int64_t)KT * 4;
     const int64_t total = (int64_t)rows * chunks_per_row;
@@ -49,11 +49,14 @@ __global__ void __launch_bounds__(256) synth_packed_kernel(uint4* __restrict__ d
         const int kc8 = (int)(i % chunks_per_row);
         const int r = dest_row(row0, rl, ileave);
         const uint64_t base = (uint64_t)(src_row0 + rl) * (uint64_t)src_ld + (uint64_t)(src_col0 + (int64_t)kc8 * 8);
+        // the element's hidden channel without a division: src_ld is the full tensor's row length (== spec.cols)
+        const uint32_t crow = (uint32_t)(src_row0 + rl), ccol = (uint32_t)(src_col0 + (int64_t)kc8 * 8);
+        const bool by_row = spec.axis == kSynthAxisRow;
         uint32_t w[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t a = synth_bits(name_hash, base + 2 * j, kSynthMatrix);
-            const uint32_t b = synth_bits(name_hash, base + 2 * j + 1, kSynthMatrix);
+            const uint32_t a = synth_bits_chan(spec, base + 2 * j, by_row ? crow : ccol + 2 * j);
+            const uint32_t b = synth_bits_chan(spec, base + 2 * j + 1, by_row ? crow : ccol + 2 * j + 1);
             w[j] = a | (b << 16);
         }
         const int nt = r >> 4, kt = kc8 >> 2, lane = ((kc8 & 3) << 4) | (r & 15);
@@ -61,15 +64,15 @@ __global__ void __launch_bounds__(256) synth_packed_kernel(uint4* __restrict__ d
     }
 }
 
-__global__ void __launch_bounds__(256) synth_rowmajor_bf16_kernel(uint16_t* __restrict__ dst, uint64_t name_hash,
-                                                                  int kind, int64_t first, int64_t count) {
+__global__ void __launch_bounds__(256) synth_rowmajor_bf16_kernel(uint16_t* __restrict__ dst, SynthSpec spec, int64_t first,
+                                                                  int64_t count) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
-        dst[i] = synth_bits(name_hash, (uint64_t)(first + i), kind);
+        dst[i] = synth_bits(spec, (uint64_t)(first + i));
 }
-__global__ void __launch_bounds__(256) synth_rowmajor_f32_kernel(float* __restrict__ dst, uint64_t name_hash, int kind,
-                                                                 int64_t first, int64_t count) {
+__global__ void __launch_bounds__(256) synth_rowmajor_f32_kernel(float* __restrict__ dst, SynthSpec spec, int64_t first,
+                                                                 int64_t count) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
-        dst[i] = bf16_to_f32(synth_bits(name_hash, (uint64_t)(first + i), kind));
+        dst[i] = bf16_to_f32(synth_bits(spec, (uint64_t)(first + i)));
 }
 
 static inline int grid_for(int64_t n, int per_block = 256, int cap = 8192) {
@@ -85,21 +88,51 @@ hipError_t launch_pack_rows(const PackedW& dst, int row0, int rows, const bf16_b
     pack_rows_kernel<<<grid_for((int64_t)rows * KT * 4), 256, 0, s>>>(dst.data, KT, row0, rows, src, ld, ileave);
     return hipGetLastError();
 }
-hipError_t launch_synth_packed(const PackedW& dst, int row0, int rows, uint64_t name_hash, int64_t src_row0,
+hipError_t launch_synth_packed(const PackedW& dst, int row0, int rows, const SynthSpec& spec, int64_t src_row0,
                                int64_t src_col0, int64_t src_ld, int ileave, hipStream_t s) {
     const int KT = dst.K / 32;
-    synth_packed_kernel<<<grid_for((int64_t)rows * KT * 4), 256, 0, s>>>(dst.data, KT, row0, rows, name_hash, src_row0,
+    if (spec.profile != 0 && spec.axis != kSynthAxisNone && spec.cols != src_ld) return hipErrorInvalidValue;
+    synth_packed_kernel<<<grid_for((int64_t)rows * KT * 4), 256, 0, s>>>(dst.data, KT, row0, rows, spec, src_row0,
                                                                         src_col0, src_ld, ileave);
     return hipGetLastError();
 }
-hipError_t launch_synth_rowmajor_bf16(bf16_bits* dst, uint64_t name_hash, int kind, int64_t first, int64_t count,
-                                      hipStream_t s) {
-    synth_rowmajor_bf16_kernel<<<grid_for(count), 256, 0, s>>>(dst, name_hash, kind, first, count);
+hipError_t launch_synth_rowmajor_bf16(bf16_bits* dst, const SynthSpec& spec, int64_t first, int64_t count, hipStream_t s) {
+    synth_rowmajor_bf16_kernel<<<grid_for(count), 256, 0, s>>>(dst, spec, first, count);
     return hipGetLastError();
 }
-hipError_t launch_synth_rowmajor_f32(float* dst, uint64_t name_hash, int kind, int64_t first, int64_t count,
-                                     hipStream_t s) {
-    synth_rowmajor_f32_kernel<<<grid_for(count), 256, 0, s>>>(dst, name_hash, kind, first, count);
+hipError_t launch_synth_rowmajor_f32(float* dst, const SynthSpec& spec, int64_t first, int64_t count, hipStream_t s) {
+    synth_rowmajor_f32_kernel<<<grid_for(count), 256, 0, s>>>(dst, spec, first, count);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// debug: scan an f16 buffer (K / V cache) for saturated elements.  Every cache write goes through f16_sat(), which clamps
+// to +-65504 (0x7BFF): an element AT that magnitude was (with probability ~1) clamped.  Off the hot path: the kernels that
+// write the cache carry no counter.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) f16_scan_kernel(const uint4* __restrict__ data, int64_t n16, unsigned long long* sat,
+                                                       unsigned* absmax_bits) {
+    unsigned long long cnt = 0;
+    unsigned mx = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 v = data[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned a = w[j] & 0x7FFFu, b = (w[j] >> 16) & 0x7FFFu;
+            cnt += (a >= 0x7BFFu) + (b >= 0x7BFFu);  // 0x7BFF = 65504; above it: inf / NaN (never written by f16_sat of a finite value)
+            mx = max(mx, max(a, b));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o); mx = max(mx, (unsigned)__shfl_xor((int)mx, o)); }
+    if ((threadIdx.x & 63) == 0) {
+        if (cnt) atomicAdd(sat, cnt);
+        atomicMax(absmax_bits, mx);
+    }
+}
+hipError_t launch_f16_scan(const f16_bits* data, int64_t n, unsigned long long* sat, unsigned* absmax_bits, hipStream_t s) {
+    f16_scan_kernel<<<grid_for(n / 8, 256, 2048), 256, 0, s>>>(reinterpret_cast<const uint4*>(data), n / 8, sat, absmax_bits);
     return hipGetLastError();
 }
 
@@ -698,8 +731,7 @@ static hipError_t lmhead_launch_t(const bf16_bits* xh, const bf16_bits* xl, int 
 
 GemmPlan plan_lmhead(int M, int N, int K) {
     GemmPlan p = plan_gemm(M, N, K, 1);
-    static const bool off = getenv("NVLLM_NO_LMHEAD") != nullptr;
-    if (off || M > 64 || K % 256 || N % 16) return p;
+    if (M > 64 || K % 256 || N % 16) return p;
     // one workgroup (8 waves) per CU: n-tiles per wave so that the grid fits the 256 CUs in one round
     const int ntiles = N / 16;
     int nt = (ntiles + 2047) / 2048;
@@ -1117,8 +1149,7 @@ __global__ void __launch_bounds__(NWK * 64) gemm_rowdir_kernel(RowParArgs a, con
 struct RowDirShape { int nt, nwk, tk; };
 static RowDirShape rowdir_shape(int N, int K, int epi, int M) {
     RowDirShape none{0, 0, 0};
-    static const bool off = getenv("NVLLM_NO_ROWDIR") != nullptr;
-    if (off || N % 16 || K % 32 || M > 128) return none;
+    if (N % 16 || K % 32 || M > 128) return none;
     const int KT = K / 32, ntiles = N / 16;
     if (KT % 16 || KT / 16 < 2 || KT / 16 > 8 || (KT / 16) % 2) return none;  // K in {1024, 2048, 3072, 4096}
     const int tk = KT / 16;
@@ -2290,9 +2321,7 @@ hipError_t launch_attn_paged(const AttnArgs& a, int n_tiles, int qt, int rows, i
     hipError_t e = hipErrorInvalidValue;
     const bool fused = a.qkv != nullptr;  // decode rows straight from the QKV GEMM's slabs
     if (fused && (qt != 1 || n_tiles != rows)) return hipErrorInvalidValue;  // fused decode: tile i is row i
-    static const int decode_waves = [] { const char* e = getenv("NVLLM_ATTN_WAVES"); return e ? atoi(e) : 4; }();
-    if (a.kv.hd == 128 && qt == 1 && decode_waves == 8) e = fused ? attn_launch_t<128, 1, 8, true>(b, n_tiles, gz, s) : attn_launch_t<128, 1, 8, false>(b, n_tiles, gz, s);
-    else if (a.kv.hd == 128 && qt == 1) e = fused ? attn_launch_t<128, 1, 4, true>(b, n_tiles, gz, s) : attn_launch_t<128, 1, 4, false>(b, n_tiles, gz, s);
+    if (a.kv.hd == 128 && qt == 1) e = fused ? attn_launch_t<128, 1, 4, true>(b, n_tiles, gz, s) : attn_launch_t<128, 1, 4, false>(b, n_tiles, gz, s);
     else if (a.kv.hd == 128 && qt == 2) e = attn_launch_t<128, 2, 4, false>(b, n_tiles, gz, s);
     else if (a.kv.hd == 64 && qt == 1) e = fused ? attn_launch_t<64, 1, 4, true>(b, n_tiles, gz, s) : attn_launch_t<64, 1, 4, false>(b, n_tiles, gz, s);
     else if (a.kv.hd == 64 && qt == 2) e = attn_launch_t<64, 2, 4, false>(b, n_tiles, gz, s);

@@ -59,8 +59,7 @@ hipError_t launch_oneshot_push(const float* src, size_t n, const OneShotPeers& p
     return hipGetLastError();
 }
 
-hipError_t launch_oneshot_wait(const uint32_t* flags, int tp, int gen, uint32_t seq, int* err, hipStream_t s) {
-    static const long long max_spins = getenv("NVLLM_ONESHOT_SPINS") ? atoll(getenv("NVLLM_ONESHOT_SPINS")) : 20000000LL;  // ~ seconds, not forever
+hipError_t launch_oneshot_wait(const uint32_t* flags, int tp, int gen, uint32_t seq, int* err, long long max_spins, hipStream_t s) {
     oneshot_wait_kernel<<<1, 64, 0, s>>>(flags, tp, gen, seq, err, max_spins);
     return hipGetLastError();
 }

@@ -290,8 +290,7 @@ __global__ void __launch_bounds__(512) gemm_stream_kernel(StreamArgs a, const ui
 struct StreamShape { int nt, ks, kc; };
 static StreamShape stream_shape(int M, int N, int K, int epi, bool any_size) {
     StreamShape none{0, 0, 0};
-    static const bool off = getenv("NVLLM_NO_STREAM") != nullptr;
-    if (off || M <= 16 || M > 64 || N % 16 || K % 32) return none;
+    if (M <= 16 || M > 64 || N % 16 || K % 32) return none;
     if (!any_size && (size_t)N * K * 2 < ((size_t)24 << 20)) return none;  // small matrices: whole-K kernels when they apply
     if (epi == 2 && (N / 16) % 2) return none;
     const int KT = K / 32, ntiles = N / 16;
@@ -328,7 +327,7 @@ static hipError_t stream_launch_t(const StreamShape& sh, const StreamArgs& a, co
     const size_t lds = (size_t)2 * (2 * 4 * KC) * 1024;
     const int waves = (w.N / 16 + NT - 1) / NT;
     dim3 grid((waves + 7) / 8, sh.ks);
-    static const size_t nt_min_bytes = (size_t)(getenv("NVLLM_STREAM_NT_MB") ? atoi(getenv("NVLLM_STREAM_NT_MB")) : 80) << 20;  // A/B switch
+    constexpr size_t nt_min_bytes = (size_t)80 << 20;  // measured: 32B shards gain from 80 MB up, 8B matrices below lose
     if (w.bytes() >= nt_min_bytes) {  // big matrix: non-temporal weight stream
         static std::atomic<uint64_t> lds_set_nt{0};
         ensure_dyn_lds(reinterpret_cast<const void*>(gemm_stream_kernel<NT, SC, KC, EPI, true>), lds, lds_set_nt);

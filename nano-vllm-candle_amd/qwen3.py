@@ -167,9 +167,11 @@ class Qwen3ForCausalLM:
         return m
 
     @classmethod
-    def from_synthetic(cls, cfg, seed=0, ctx=None):
+    def from_synthetic(cls, cfg, seed=0, ctx=None, profile=0):
+        """weights from the deterministic generator, straight into HBM; profile 1 = heavy-tailed Qwen3-like statistics
+        (include/nvllm_amd.h nvllm_model_fill_synthetic_profile)"""
         m = cls(cfg, ctx)
-        _lib.check(_lib.lib().nvllm_model_fill_synthetic(m.h, seed), m.ctx.h)
+        _lib.check(_lib.lib().nvllm_model_fill_synthetic_profile(m.h, seed, profile), m.ctx.h)
         m.finalize()
         return m
 

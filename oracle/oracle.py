@@ -79,6 +79,9 @@ def lib():
         L.oq3_set_tensor.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_int64]
         L.oq3_get_tensor.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_int64]
         L.oq3_fill_synthetic.argtypes = [C.c_void_p, C.c_uint64]
+        L.oq3_fill_synthetic_profile.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+        L.oq3_synth_bf16_spec.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int64,
+                                          C.c_int64, C.POINTER(C.c_uint16)]
         L.oq3_synth_bf16.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_uint16)]
         L.oq3_set_trace.argtypes = [C.c_void_p, fp, fp]
         L.oq3_forward.argtypes = [C.c_void_p, u32p, C.c_int, C.c_int, fp]
@@ -95,6 +98,7 @@ def lib():
         L.oq3_tp_shard_offset.restype = C.c_int64
         L.oq3_tp_shard_offset.argtypes = [C.c_int64, C.c_int, C.c_int]
         L.oq3_argmax_last.argtypes = [fp, C.c_int]
+        L.oq3_set_study.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -168,9 +172,20 @@ def argmax_last(v):
     return int(lib().oq3_argmax_last(_fp(v), v.size))
 
 
-def synth_bf16(name, seed, kind, first, count):
+def set_study(flags):
+    """numerics-study knob of the attention core (qwen3_oracle.c oq3_set_study; 0 = reference arithmetic, the default)"""
+    lib().oq3_set_study(int(flags))
+
+
+def synth_bf16(name, seed, kind, first, count, profile=0, axis=0, cols=1, hidden_size=1):
+    """bf16 bits of elements [first, first+count) of tensor `name` (oracle/synth.h): kind 0 matrix / 1 norm / 2 q,k-norm;
+    profile 1 also needs where the hidden channel sits (axis 1: idx % cols, 2: idx // cols) and hidden_size"""
     out = np.empty(count, np.uint16)
-    lib().oq3_synth_bf16(name.encode(), seed, kind, first, count, out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    if profile == 0:
+        lib().oq3_synth_bf16(name.encode(), seed, kind, first, count, out.ctypes.data_as(C.POINTER(C.c_uint16)))
+    else:
+        lib().oq3_synth_bf16_spec(name.encode(), seed, kind, profile, axis, cols, hidden_size, first, count,
+                                  out.ctypes.data_as(C.POINTER(C.c_uint16)))
     return out
 
 
@@ -195,8 +210,9 @@ class Model:
             lib().oq3_destroy(self._h)
             self._h = None
 
-    def fill_synthetic(self, seed=0):
-        lib().oq3_fill_synthetic(self._h, seed)
+    def fill_synthetic(self, seed=0, profile=0):
+        """profile 0: the benign generator; 1: heavy-tailed Qwen3-like statistics (oracle/synth.h)"""
+        lib().oq3_fill_synthetic_profile(self._h, seed, profile)
         return self
 
     def set_tensor(self, name, arr):

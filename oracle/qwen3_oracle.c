@@ -205,6 +205,40 @@ OQ3_API void oq3_rope_apply(float* x, int B, int heads, int T, int hd, float bas
     free(cosv); free(sinv);
 }
 
+/* NUMERICS STUDY knob (tests/tools only; 0 = the reference's arithmetic, the default and the only mode parity tests use):
+ * rounds chosen operands of the attention core the way a reduced-precision KV cache would, so the share of each rounding
+ * in a logits error can be measured on the CPU at full model size (tools/numerics_study.py).
+ * bit 0: K -> f16, bit 1: V -> f16, bit 2: unnormalised P = exp(s - max) -> f16, bit 3: K -> bf16, bit 4: V -> bf16,
+ * bit 5: K -> f16 hi + f16 lo (22 bits), bit 6: V -> f16 hi + f16 lo, bit 7: P -> bf16 hi + bf16 lo,
+ * bit 8: V -> f16 hi + e5m2 lo (the residual's f16 bits cut to their top byte, round to nearest even): 24-bit V. */
+static int g_study = 0;
+OQ3_API void oq3_set_study(int flags) { g_study = flags; }
+static float study_f16(float x) {
+    if (!(fabsf(x) < 65504.f)) return x > 0 ? 65504.f : (x < 0 ? -65504.f : x);
+    if (fabsf(x) < 6.103515625e-05f) return rintf(x * 16777216.f) / 16777216.f; /* subnormal f16: multiples of 2^-24 */
+    union { float f; uint32_t u; } c; c.f = x;
+    c.u += 0xFFFu + ((c.u >> 13) & 1u); c.u &= ~0x1FFFu;
+    return c.f;
+}
+static float study_bf16(float x) {
+    union { float f; uint32_t u; } c; c.f = x;
+    c.u += 0x7FFFu + ((c.u >> 16) & 1u); c.u &= 0xFFFF0000u;
+    return c.f;
+}
+static float study_e5m2(float r) { /* f16(r) rounded to its top 8 bits (sign, 5 exponent, 2 mantissa) */
+    r = study_f16(r);
+    if (fabsf(r) < 6.103515625e-05f) return rintf(r * 65536.f) / 65536.f; /* f16 subnormals: top byte keeps multiples of 2^-16 */
+    union { float f; uint32_t u; } c; c.f = r;
+    c.u += 0xFFFFFu + ((c.u >> 21) & 1u); c.u &= ~0x1FFFFFu;
+    return c.f;
+}
+static float study_round(float x, int f16, int bf16, int f16x2) {
+    if (f16x2) { const float h = study_f16(x); return h + study_f16(x - h); }
+    if (f16) return study_f16(x);
+    if (bf16) return study_bf16(x);
+    return x;
+}
+
 /* attention core, src/models/qwen3.rs:236-277: q [B,nh,T,hd], k,v [B,kv,T,hd] -> ctx [B*T, nh*hd].
  * GQA interleaved expand (q head h uses kv head h/(nh/kv), :241-256), scores*scale (:259),
  * additive mask -1e9 for j>i (:260-271), f32 softmax (:272-273), p.v (:275). */
@@ -212,6 +246,23 @@ OQ3_API void oq3_attention(const float* q, const float* k, const float* v, int B
                            float* ctx) {
     const float scale = powf((float)hd, -0.5f); /* qwen3.rs:134 */
     const int rep = nh / kv;
+    float *ks = NULL, *vs = NULL;
+    if (g_study & (1 | 8 | 32)) {
+        const size_t n = (size_t)B * kv * T * hd;
+        ks = (float*)malloc(sizeof(float) * n);
+        for (size_t i = 0; i < n; ++i) ks[i] = study_round(k[i], g_study & 1, g_study & 8, g_study & 32);
+        k = ks;
+    }
+    if (g_study & (2 | 16 | 64 | 256)) {
+        const size_t n = (size_t)B * kv * T * hd;
+        vs = (float*)malloc(sizeof(float) * n);
+        for (size_t i = 0; i < n; ++i) {
+            if (g_study & 256) { const float h = study_f16(v[i]); vs[i] = h + study_e5m2(v[i] - h); }
+            else vs[i] = study_round(v[i], g_study & 2, g_study & 16, g_study & 64);
+        }
+        v = vs;
+    }
+    const int study_p = g_study & (4 | 128);
 #pragma omp parallel
     {
         float* sc = (float*)malloc(sizeof(float) * (size_t)T);
@@ -233,6 +284,11 @@ OQ3_API void oq3_attention(const float* q, const float* k, const float* v, int B
                     }
                     float sum = 0.f;
                     for (int j = 0; j <= i; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+                    if (study_p) /* the sum stays f32 (as an f32 row sum of the unrounded P would); only the P.V operand is rounded */
+                        for (int j = 0; j <= i; ++j) {
+                            if (study_p & 4) sc[j] = study_f16(sc[j]);
+                            else { const float h = study_bf16(sc[j]); sc[j] = h + study_bf16(sc[j] - h); }
+                        }
                     float* out = ctx + ((size_t)(b * T + i) * nh + h) * hd;
                     for (int d = 0; d < hd; ++d) out[d] = 0.f;
                     for (int j = 0; j <= i; ++j) {
@@ -246,6 +302,7 @@ OQ3_API void oq3_attention(const float* q, const float* k, const float* v, int B
             }
         free(sc);
     }
+    free(ks); free(vs);
 }
 
 /* TPConfig shard arithmetic, src/tp.rs:59-65 */
@@ -302,14 +359,15 @@ OQ3_API void oq3_destroy(oq3_model* m) {
 
 /* Resolve an HF tensor name (qwen3.rs:150,156,162,168,178,184,304,308,313,353,360,432,444,526) to
  * its destination inside the (fused) oracle tensors.  Returns NULL on unknown name. */
-static float* resolve(oq3_model* m, const char* name, size_t* numel, int* kind) {
+static float* resolve_ex(oq3_model* m, const char* name, size_t* numel, int* kind, int* axis, int64_t* cols) {
     const oq3_config* c = &m->cfg;
     const size_t H = c->hidden_size, V = c->vocab_size, hd = c->head_dim, I = c->intermediate_size;
     const size_t nh = c->num_attention_heads, kv = c->num_key_value_heads;
     *kind = SYNTH_KIND_MATRIX;
-    if (!strcmp(name, "model.embed_tokens.weight")) { *numel = V * H; return m->embed; }
+    *axis = SYNTH_AXIS_NONE; *cols = 1;  /* where the hidden channel sits (oracle/synth.h, profile 1) */
+    if (!strcmp(name, "model.embed_tokens.weight")) { *numel = V * H; *axis = SYNTH_AXIS_COL; *cols = (int64_t)H; return m->embed; }
     if (!strcmp(name, "lm_head.weight")) { *numel = V * H; return m->lm_head; }
-    if (!strcmp(name, "model.norm.weight")) { *numel = H; *kind = SYNTH_KIND_NORM; return m->norm; }
+    if (!strcmp(name, "model.norm.weight")) { *numel = H; *kind = SYNTH_KIND_NORM; *axis = SYNTH_AXIS_COL; *cols = (int64_t)H; return m->norm; }
     int l = -1, off = 0;
     if (sscanf(name, "model.layers.%d.%n", &l, &off) != 1 || l < 0 || l >= c->num_hidden_layers) return NULL;
     const char* s = name + off;
@@ -317,16 +375,21 @@ static float* resolve(oq3_model* m, const char* name, size_t* numel, int* kind) 
     if (!strcmp(s, "self_attn.q_proj.weight")) { *numel = nh * hd * H; return L->w_qkv; }
     if (!strcmp(s, "self_attn.k_proj.weight")) { *numel = kv * hd * H; return L->w_qkv + nh * hd * H; }
     if (!strcmp(s, "self_attn.v_proj.weight")) { *numel = kv * hd * H; return L->w_qkv + (nh + kv) * hd * H; }
-    if (!strcmp(s, "self_attn.o_proj.weight")) { *numel = H * nh * hd; return L->w_o; }
+    if (!strcmp(s, "self_attn.o_proj.weight")) { *numel = H * nh * hd; *axis = SYNTH_AXIS_ROW; *cols = (int64_t)(nh * hd); return L->w_o; }
     if (!strcmp(s, "mlp.gate_proj.weight")) { *numel = I * H; return L->w_gu; }
     if (!strcmp(s, "mlp.up_proj.weight")) { *numel = I * H; return L->w_gu + I * H; }
-    if (!strcmp(s, "mlp.down_proj.weight")) { *numel = H * I; return L->w_down; }
+    if (!strcmp(s, "mlp.down_proj.weight")) { *numel = H * I; *axis = SYNTH_AXIS_ROW; *cols = (int64_t)I; return L->w_down; }
     *kind = SYNTH_KIND_NORM;
-    if (!strcmp(s, "input_layernorm.weight")) { *numel = H; return L->ln1; }
-    if (!strcmp(s, "post_attention_layernorm.weight")) { *numel = H; return L->ln2; }
+    if (!strcmp(s, "input_layernorm.weight")) { *numel = H; *axis = SYNTH_AXIS_COL; *cols = (int64_t)H; return L->ln1; }
+    if (!strcmp(s, "post_attention_layernorm.weight")) { *numel = H; *axis = SYNTH_AXIS_COL; *cols = (int64_t)H; return L->ln2; }
+    *kind = SYNTH_KIND_QKNORM;
     if (!strcmp(s, "self_attn.q_norm.weight")) { *numel = hd; return L->qn; }
     if (!strcmp(s, "self_attn.k_norm.weight")) { *numel = hd; return L->kn; }
     return NULL;
+}
+static float* resolve(oq3_model* m, const char* name, size_t* numel, int* kind) {
+    int axis; int64_t cols;
+    return resolve_ex(m, name, numel, kind, &axis, &cols);
 }
 
 /* load one HF-named tensor from f32 host data ([out,in] row-major); 0 = ok */
@@ -347,21 +410,24 @@ OQ3_API int oq3_get_tensor(oq3_model* m, const char* name, float* out, int64_t n
     return 0;
 }
 
-static void fill_one(oq3_model* m, const char* name, uint64_t seed) {
-    size_t n; int kind;
-    float* dst = resolve(m, name, &n, &kind);
+static void fill_one(oq3_model* m, const char* name, uint64_t seed, int profile) {
+    size_t n;
+    synth_spec sp;
+    float* dst = resolve_ex(m, name, &n, &sp.kind, &sp.axis, &sp.cols);
     if (!dst) { fprintf(stderr, "oq3: bad tensor name %s\n", name); abort(); }
-    uint64_t nh = synth_name_hash(name, seed);
+    sp.name_hash = synth_name_hash(name, seed);
+    sp.profile = profile;
+    synth_outlier_channels(seed, m->cfg.hidden_size, sp.ch);
 #pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < n; ++i) dst[i] = synth_value(nh, i, kind);
+    for (size_t i = 0; i < n; ++i) dst[i] = synth_spec_value(&sp, i);
 }
 
-/* fill every tensor from the deterministic generator (oracle/synth.h) */
-OQ3_API void oq3_fill_synthetic(oq3_model* m, uint64_t seed) {
+/* fill every tensor from the deterministic generator (oracle/synth.h); profile 0 = benign, 1 = heavy */
+OQ3_API void oq3_fill_synthetic_profile(oq3_model* m, uint64_t seed, int profile) {
     char name[128];
-    fill_one(m, "model.embed_tokens.weight", seed);
-    fill_one(m, "lm_head.weight", seed);
-    fill_one(m, "model.norm.weight", seed);
+    fill_one(m, "model.embed_tokens.weight", seed, profile);
+    fill_one(m, "lm_head.weight", seed, profile);
+    fill_one(m, "model.norm.weight", seed, profile);
     static const char* per_layer[] = {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
                                       "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight",
                                       "mlp.down_proj.weight", "input_layernorm.weight",
@@ -370,14 +436,26 @@ OQ3_API void oq3_fill_synthetic(oq3_model* m, uint64_t seed) {
     for (int l = 0; l < m->cfg.num_hidden_layers; ++l)
         for (size_t k = 0; k < sizeof(per_layer) / sizeof(per_layer[0]); ++k) {
             snprintf(name, sizeof name, "model.layers.%d.%s", l, per_layer[k]);
-            fill_one(m, name, seed);
+            fill_one(m, name, seed, profile);
         }
 }
+OQ3_API void oq3_fill_synthetic(oq3_model* m, uint64_t seed) { oq3_fill_synthetic_profile(m, seed, 0); }
 
 /* raw generator access for tests (bit-equality with the device generator) */
 OQ3_API void oq3_synth_bf16(const char* name, uint64_t seed, int kind, int64_t first, int64_t count, uint16_t* out) {
-    uint64_t nh = synth_name_hash(name, seed);
-    for (int64_t i = 0; i < count; ++i) out[i] = synth_bf16_bits(nh, (uint64_t)(first + i), kind);
+    synth_spec sp;
+    memset(&sp, 0, sizeof sp);
+    sp.name_hash = synth_name_hash(name, seed); sp.kind = kind;
+    for (int64_t i = 0; i < count; ++i) out[i] = synth_spec_bits(&sp, (uint64_t)(first + i));
+}
+/* the same for any profile: axis / cols / hidden_size say where the hidden channel of an element sits (synth.h) */
+OQ3_API void oq3_synth_bf16_spec(const char* name, uint64_t seed, int kind, int profile, int axis, int64_t cols, int hidden_size,
+                                 int64_t first, int64_t count, uint16_t* out) {
+    synth_spec sp;
+    memset(&sp, 0, sizeof sp);
+    sp.name_hash = synth_name_hash(name, seed); sp.kind = kind; sp.profile = profile; sp.axis = axis; sp.cols = cols > 0 ? cols : 1;
+    synth_outlier_channels(seed, hidden_size > 0 ? hidden_size : 1, sp.ch);
+    for (int64_t i = 0; i < count; ++i) out[i] = synth_spec_bits(&sp, (uint64_t)(first + i));
 }
 
 OQ3_API void oq3_set_trace(oq3_model* m, float* h_per_layer, float* res_per_layer) {

@@ -360,3 +360,72 @@ def test_concurrent_prompt_chunks_are_bit_equal_to_a_solo_run(pkg):
     m0.close()
     c0.close()
     assert not bad, bad
+
+
+def test_0_6b_single_sequence_256_token_decode_vs_oracle(pkg, ctx, oracle_0_6b):
+    # BASELINE configs[1]: Qwen3-0.6B, ONE sequence, prompt 128, 256 decode tokens (the loop of llm_engine.rs:270-325 at
+    # max_num_seqs = 1).  The device-feedback decode (nvllm_decode_next: the path `bench.py --batch 1` times) produces the
+    # tokens; at steps {0, 1, 64, 128, 255} the same position is recomputed with logits and compared with the oracle's
+    # dense no-KV-cache forward of the whole prefix (teacher-forced with the tokens the GPU produced).
+    cfg, om = oracle_0_6b
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
+    m.kv_alloc(num_blocks=3, max_seqs=1, max_batched_tokens=512)
+    rng = np.random.default_rng(128)
+    seq = rng.integers(0, cfg.vocab_size, 128).tolist()
+    worst = {}
+    ids, lg = m.step([0], [seq], True, want_logits=True)
+    for step in range(256):
+        if step > 0:
+            nxt = m.decode_next()[:1]
+            if step in (1, 64, 128, 255):
+                ids, lg = m.step([0], [seq], False, want_logits=True)  # recomputes the position decode_next has just produced
+                assert ids.tolist() == nxt.tolist()
+            else:
+                ids = nxt
+        if step in (0, 1, 64, 128, 255):
+            rid, rlg = om.run_greedy([seq])
+            worst[step] = check_rows(f"0.6B x28 layers, batch 1, context {len(seq)}, decode step {step}", ids, lg, rid, rlg)
+        seq.append(int(ids[0]))
+    assert len(seq) == 128 + 256
+    print("[parity] 0.6B batch 1, 256 decode tokens, worst error per checked step:", {k: f"{v:.2e}" for k, v in worst.items()})
+    m.close()
+
+
+def test_8b_full_size_batch256_context4096_properties(pkg, ctx):
+    # BASELINE configs[3] at FULL size: Qwen3-8B (36 layers, vocabulary 151936), 256 live sequences of 4096 tokens, KV pool
+    # of 256 x 17 blocks (162 GB of the 288 GB) -- far beyond what the oracle can re-run, so the size-independent properties
+    # test_full_size_batch64_properties checks for 0.6B: finite logits, device arg-max == last max of its logits
+    # (llm_engine.rs:135-142), two long sequences alone vs inside the batch, deterministic replay.
+    from tests.util import rel_err
+
+    cfg = pkg.Qwen3Config.qwen3_8b()
+    B, T = 256, 4096
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
+    m.kv_alloc(num_blocks=B * 17 + 40, max_seqs=B, max_batched_tokens=4096)
+    rng = np.random.default_rng(8)
+    prompts = [rng.integers(0, cfg.vocab_size, T, dtype=np.uint32).tolist() for _ in range(B)]
+    sids = list(range(B))
+    ids0, _ = m.step(sids, prompts, True)  # 1.05 M prompt tokens through 4096-row chunks
+    for p, t in zip(prompts, ids0):
+        p.append(int(t))
+    ids, lg = m.step(sids, prompts, False, want_logits=True)  # the 256-row decode step at context 4097
+    assert np.isfinite(lg).all() and lg.var() > 0.05
+    assert ids.tolist() == [int(np.flatnonzero(r == r.max())[-1]) for r in lg]
+    # deterministic replay: the same step again recomputes the same position from the same cache
+    ids_b, lg_b = m.step(sids, prompts, False, want_logits=True)
+    assert np.array_equal(lg, lg_b) and ids.tolist() == ids_b.tolist()
+    # the device-feedback decode continues with the ids the host-fed step produced
+    nxt = m.decode_next()[:B].copy()
+    for p, t in zip(prompts, ids):
+        p.append(int(t))
+    ids2, _ = m.step(sids, prompts, False)
+    assert ids2.tolist() == nxt.tolist()
+    # two long sequences alone (split-KV over many workgroups, 2-row GEMMs) vs inside the batch of 256
+    alone = [3, 200]
+    for j, i in enumerate(alone):
+        _, l1 = m.step([1000 + j], [prompts[i][:T + 1]], True, want_logits=True)  # fresh sequence ids: own blocks
+        e = rel_err(l1[0], lg[i])
+        print(f"[parity] 8B full size: sequence {i} (4097 tokens) alone vs inside the batch of 256: {e:.3e} (bound 5e-4)")
+        assert e < 5e-4
+        m.seq_free(1000 + j)
+    m.close()

@@ -99,3 +99,77 @@ def test_tp_prompt_chunk_through_the_tile_gemm(oracle, fuse_qk):
             assert ids.tolist() == rid.tolist(), (rank, step)
         for s, t in zip(ref_seqs, rid):
             s.append(int(t))
+
+
+def test_oneshot_allreduce_gives_up_with_an_error_code_on_every_rank(oracle):
+    # The give-up path of the one-shot all-reduce (csrc/oneshot.hip), run ONCE: rank 2 of a TP = 4 loopback group "forgets"
+    # one push during a decode step; its peers' wait kernels (and its own: it polls its own flag too) must hit their spin
+    # bound instead of hanging the stream, every rank must return NVLLM_ERCCL from that step -- the error words are gathered
+    # so that nobody leaves early and strands the others in the (max, index) gather -- and the group must be usable again:
+    # a following kv_alloc + prefill + decode on the loopback communicator's own all-reduce matches the oracle.
+    import time
+
+    import nano_vllm_candle_amd as pkg
+
+    cfg = pkg.Qwen3Config.tiny(hidden_size=256, num_attention_heads=8, num_key_value_heads=4, head_dim=64,
+                               intermediate_size=512, num_hidden_layers=2, vocab_size=1024)
+    rng = np.random.default_rng(3)
+    seqs = [rng.integers(0, cfg.vocab_size, n).tolist() for n in (9, 21, 5)]
+    tp = 4
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(4)
+    results, errors = [None] * tp, []
+
+    def worker(rank):
+        try:
+            ctx = pkg.Context(0, tp_rank=rank, tp_size=tp, loopback_group="giveup")
+            m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=4, ctx=ctx)
+            m.set_option("oneshot_allreduce", 1)
+            m.set_option("oneshot_spins", 20000)  # ~ milliseconds instead of seconds
+            m.kv_alloc(8, 4, 64)
+            my = [list(s) for s in seqs]
+            ids, _ = m.step([0, 1, 2], my, True)
+            for s, t in zip(my, ids):
+                s.append(int(t))
+            assert m.counter("oneshot_calls") > 0
+            if rank == 2:
+                m.set_option("oneshot_skip_push", 1)
+            t0 = time.perf_counter()
+            code = None
+            try:
+                m.step([0, 1, 2], my, False)
+            except pkg._lib.NvllmError as e:
+                code = e.code
+            dt = time.perf_counter() - t0
+            # afterwards: fresh pool on the communicator's all-reduce, same sequences from scratch
+            m.set_option("oneshot_allreduce", 0)
+            m.kv_alloc(8, 4, 64)
+            my = [list(s) for s in seqs]
+            out = []
+            for step in range(3):
+                ids, lg = m.step([0, 1, 2], my, step == 0, want_logits=True)
+                out.append((ids.copy(), lg.copy()))
+                for s, t in zip(my, ids):
+                    s.append(int(t))
+            results[rank] = (code, dt, out)
+            m.close()
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(tp)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert all(r is not None for r in results), "a rank hung"
+    assert [r[0] for r in results] == [pkg._lib.ERCCL] * tp, [r[0] for r in results]
+    assert max(r[1] for r in results) < 20.0, [r[1] for r in results]  # promptly: bounded spins, not a stuck stream
+    ref = [list(s) for s in seqs]
+    for step in range(3):
+        rid, rlg = om.run_greedy(ref)
+        for rank in range(tp):
+            ids, lg = results[rank][2][step]
+            assert row_rel_err(lg, rlg) < LOGITS_TOL and ids.tolist() == rid.tolist(), (rank, step)
+        for s, t in zip(ref, rid):
+            s.append(int(t))

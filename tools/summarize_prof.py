@@ -77,7 +77,7 @@ if ks and prof_bench:
                 rows.append((k, int(row["Calls"]), avg_us, alg[k], gbs, gbs / HBM_PEAK, fetch.get(k), pmc_alg.get(k)))
     dst = os.path.join(out, f"r{rnd}_decode_kernels.csv")
     with open(dst, "w") as g:
-        g.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --skip-tp-leg --profile-steps 0 (MI355X, {prof_bench['config']['workload']})\n"
+        g.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --skip-tp-leg (the driver's command; MI355X, {prof_bench['config']['workload']})\n"
                 f"# avg_us: all launches of the run ({info['steps']} decode steps); algorithmic_bytes: mean over the SAME launches; frac = GB/s / {HBM_PEAK:.0f}\n"
                 "# fetch_bytes: separate --pmc FETCH_SIZE pass (x2 gfx950 correction), quoted with that pass's own algorithmic bytes\n"
                 "kernel,launches,avg_us,algorithmic_bytes_per_launch,achieved_GBps,frac_of_hbm_peak,fetch_bytes_per_launch_pmc_pass,algorithmic_bytes_pmc_pass\n")
@@ -88,8 +88,8 @@ if ks and prof_bench:
     print("wrote", dst)
     dom = "attn_paged_kernel<128, 1, 4, true>"
     if dom in fetch and pmc_bench:
-        js = {"_comment": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --skip-tp-leg --profile-steps 0 "
-                          "on MI355X; FETCH_SIZE KB x 2 (gfx950 wide-stream correction, MI355X_MICROARCH.md HBM section) x 1024; algorithmic = mean over "
+        js = {"_comment": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --skip-tp-leg "
+                          "(the driver's command) on MI355X; FETCH_SIZE KB x 2 (gfx950 wide-stream correction, MI355X_MICROARCH.md HBM section) x 1024; algorithmic = mean over "
                           f"the same run's launches. Full table: r{rnd}_decode_kernels.csv",
               dom: {"fetch_bytes_per_launch": int(round(fetch[dom])), "algorithmic_bytes_per_launch": int(pmc_alg[dom])}}
         dst = os.path.join(out, f"r{rnd}_pmc_fetch_size.json")
