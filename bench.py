@@ -465,7 +465,7 @@ def main():
     if dom == "attn":
         # algorithmic bytes of one launch = every attended token's K and V of this layer, read once
         dom_bytes = float(np.mean(attn_ctx)) * kv_layer
-        dom_name = "attn_paged_kernel<128, 1, 4, true>"
+        dom_name = "attn_paged_kernel<128, 1, 4, true, false>"
     elif dom == "lm_head":
         dom_bytes = float(lm_bytes)
         dom_name = "lmhead_kernel"

@@ -442,6 +442,7 @@ struct nvllm_model {
     // KV pool
     int num_blocks = 0, max_seqs = 0, max_blocks = 0, max_rows = 0;
     std::vector<f16_bits*> kcache, vcache;
+    std::vector<uint8_t*> vlocache;  // 24-bit V (opt_kv_v_bits == 24): one residual byte per V element, else empty
     std::vector<int> free_blocks, free_slots;
     std::unordered_map<int64_t, SeqState> seqs;
     int* d_block_tables = nullptr;
@@ -461,6 +462,7 @@ struct nvllm_model {
     // per n-group reads every slab behind an agent-scope release of all the others.  nvllm_debug_set_option turns it on.
     int opt_stream_combine = 0;
     int opt_oneshot_allreduce = 0;  // TP decode: one-shot all-reduce instead of the communicator's (set before kv_alloc; opt-in)
+    int opt_kv_v_bits = 16;            // 24: V as f16 + e5m2 residual (13..14 significant bits, V bytes x1.5); read at kv_alloc
     int opt_oneshot_skip_push = 0;     // test hook: this rank "forgets" its next N pushes (the give-up path of its peers' waits)
     int opt_oneshot_spins = 20000000;  // bound of the one-shot wait kernel's poll (~ seconds): a missing peer is an error code
     int opt_no_fused = 0, opt_no_xpack = 0, opt_no_rowpar = 0;  // A/B switches (nvllm_debug_set_option): force the generic paths
@@ -608,7 +610,8 @@ extern "C" int nvllm_model_create(nvllm_ctx* ctx, const nvllm_qwen3_config* cfg,
 static void free_kv(nvllm_model* m) {
     for (auto p : m->kcache) (void)hipFree(p);
     for (auto p : m->vcache) (void)hipFree(p);
-    m->kcache.clear(); m->vcache.clear();
+    for (auto p : m->vlocache) (void)hipFree(p);
+    m->kcache.clear(); m->vcache.clear(); m->vlocache.clear();
     void* ptrs[] = {m->d_block_tables, m->d_ids, m->d_pos, m->d_slot, m->d_tile_row0, m->d_tile_nrows, m->d_tile_slot,
                     m->d_last_rows, m->d_tile_order, m->d_tile_last, m->d_group_order, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->xh2, m->xl2, m->ctxh, m->ctxl, m->ssqA, m->ssqB, m->d_next,
                     m->part_val, m->part_idx, m->argmax_scratch, m->attn_po, m->attn_pml, m->tap_h, m->tap_res, m->cosv, m->sinv, m->tickets, m->qkv_out, m->d_keys, m->d_temps};
@@ -864,11 +867,17 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     const int by_pos = (m->cfg.max_position_embeddings + kBlockTokens - 1) / kBlockTokens;
     m->max_blocks = std::max(1, std::min(num_blocks, by_pos));
     const size_t per_layer = (size_t)num_blocks * m->kv_l * kBlockTokens * m->hd;
+    if (m->opt_kv_v_bits == 24 && m->hd != 128) return fail(ctx, NVLLM_EINVAL, "kv_v_bits = 24 needs head_dim 128");
     m->kcache.assign(m->L, nullptr);
     m->vcache.assign(m->L, nullptr);
+    if (m->opt_kv_v_bits == 24) m->vlocache.assign(m->L, nullptr);
     for (int l = 0; l < m->L; ++l) {
         HIPCHK(ctx, hipMalloc((void**)&m->kcache[l], per_layer * 2));
         HIPCHK(ctx, hipMalloc((void**)&m->vcache[l], per_layer * 2));
+        if (!m->vlocache.empty()) {
+            HIPCHK(ctx, hipMalloc((void**)&m->vlocache[l], per_layer));
+            HIPCHK(ctx, hipMemsetAsync(m->vlocache[l], 0, per_layer, ctx->stream));
+        }
         // zero once: masked lanes multiply P = 0 with whatever the block holds; 0 * finite = 0 needs finite data
         HIPCHK(ctx, hipMemsetAsync(m->kcache[l], 0, per_layer * 2, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(m->vcache[l], 0, per_layer * 2, ctx->stream));
@@ -958,7 +967,9 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
 
 extern "C" int nvllm_kv_num_free_blocks(const nvllm_model* m) { return m ? (int)m->free_blocks.size() : 0; }
 extern "C" int64_t nvllm_kv_bytes_per_token(const nvllm_model* m) {
-    return m ? (int64_t)2 * m->kv_l * m->hd * 2 * m->L : 0;
+    if (!m) return 0;
+    const int64_t v_bytes = m->vlocache.empty() ? 2 : 3;  // 24-bit V: + one residual byte per element
+    return (int64_t)m->kv_l * m->hd * (2 + v_bytes) * m->L;
 }
 
 static void release_seq(nvllm_model* m, SeqState& s) {
@@ -1202,6 +1213,7 @@ static int forward_chunk_fused(nvllm_model* m, const FusedPlan& fp, int R, int n
         qa.q_scale = powf((float)hd, -0.5f) * 1.4426950408889634f;
         qa.q_out = m->qbuf; qa.rn = rn;
         qa.kv.k = m->kcache[l]; qa.kv.v = m->vcache[l]; qa.kv.kv_l = m->kv_l; qa.kv.hd = hd;
+        qa.kv.vlo = m->vlocache.empty() ? nullptr : m->vlocache[l];
         const bool fuse_qk = qt == 1 && n_tiles == R && !m->opt_no_attn_prologue;
         if (!fuse_qk) PROF(m, PROF_QK, launch_qk_norm_rope_kvwrite(qa, R, s));
         AttnArgs aa;
@@ -1222,7 +1234,7 @@ static int forward_chunk_fused(nvllm_model* m, const FusedPlan& fp, int R, int n
         }
         PROF(m, PROF_EMPTY, hipSuccess);  // calibration: an event pair around nothing, at the attention launch's place
         STAMPS(aa, m);
-        if (qt == 2) PROF(m, PROF_ATTN, launch_attn_prefill(aa, n_tiles, s));
+        if (qt == 2 && !aa.kv.vlo) PROF(m, PROF_ATTN, launch_attn_prefill(aa, n_tiles, s));
         else PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
         // o_proj (+ residual + post-attention norm prep; qwen3.rs:278, :393)
         int rc = row_linear(fp.o, w.o, m->ctxh, m->ctxl, KO, w.ln2, m->ssqA, packed);
@@ -1325,7 +1337,8 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
     const int o_ks = tile_on ? gemm_tile_splits(R, H, KO, tmin, max_ks) : 0, d_ks = tile_on ? gemm_tile_splits(R, H, m->I_l, tmin, max_ks) : 0;
     const int q_ks = tile_on ? gemm_tile_splits(R, NQ, H, tmin, max_ks) : 0;
     const bool t_qkv = q_ks > 0 && (size_t)q_ks * R * NQ <= m->slab_floats;
-    const bool t_qkv_fused = t_qkv && m->opt_tile_fuse_qk && gemm_tile_qkv_ok(R, NQ, H, hd, tmin);
+    // (the fused epilogue writes V as packed f16 stores only: 24-bit V keeps the row kernel)
+    const bool t_qkv_fused = t_qkv && m->opt_tile_fuse_qk && m->vlocache.empty() && gemm_tile_qkv_ok(R, NQ, H, hd, tmin);
     const bool t_o = o_ks > 0 && (size_t)o_ks * R * H <= m->slab_floats;
     const bool t_gu = tile_on && gemm_tile_ok(R, 2 * m->I_l, H, 2, tmin);
     const bool t_down = t_gu && m->I_l % 32 == 0 && d_ks > 0 && (size_t)d_ks * R * H <= m->slab_floats;
@@ -1348,6 +1361,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         qa.q_scale = powf((float)hd, -0.5f) * 1.4426950408889634f;  // head_dim^-0.5 (qwen3.rs:134) * log2(e)
         qa.q_out = m->qbuf;
         qa.kv.k = m->kcache[l]; qa.kv.v = m->vcache[l]; qa.kv.kv_l = m->kv_l; qa.kv.hd = hd;
+        qa.kv.vlo = m->vlocache.empty() ? nullptr : m->vlocache[l];
         const bool fuse_qk = qt == 1 && n_tiles == R;  // decode: every q-tile is one row
         int rcg = NVLLM_OK;
         if (t_qkv_fused && !fuse_qk) {
@@ -1376,7 +1390,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
             parts_max = m->attn_parts_max;
         }
         STAMPS(aa, m);
-        if (qt == 2) PROF(m, PROF_ATTN, launch_attn_prefill(aa, n_tiles, s));
+        if (qt == 2 && !aa.kv.vlo) PROF(m, PROF_ATTN, launch_attn_prefill(aa, n_tiles, s));
         else PROF(m, PROF_ATTN, launch_attn_paged(aa, n_tiles, qt, R, parts_max, s));
         // output projection (qwen3.rs:278) + TP all-reduce
         int o_slabs = 1;
@@ -1705,7 +1719,7 @@ static int step_impl(nvllm_model* m, int n_seqs, const int64_t* seq_ids, const u
             p.tile_row0.push_back(r); p.tile_nrows.push_back(e - r); p.tile_slot.push_back(p.slot[r]);
             // prefill attention shares K/V between the four q-tiles of a workgroup: a sequence's tiles start on a multiple
             // of four, its last group is padded with empty tiles
-            if (qt == 2 && (e == r0 + R || row_seq[e] != row_seq[r]))
+            if (qt == 2 && m->vlocache.empty() && (e == r0 + R || row_seq[e] != row_seq[r]))
                 while (p.tile_row0.size() % kPrefillTileGroup) { p.tile_row0.push_back(r); p.tile_nrows.push_back(0); p.tile_slot.push_back(p.slot[r]); }
             r = e;
         }
@@ -1860,6 +1874,10 @@ extern "C" int nvllm_debug_set_option(nvllm_model* m, const char* name, int valu
     if (!strcmp(name, "stream_combine")) { m->opt_stream_combine = value; return NVLLM_OK; }
     if (!strcmp(name, "oneshot_allreduce")) { m->opt_oneshot_allreduce = value; return NVLLM_OK; }  // takes effect at the next kv_alloc
     if (!strcmp(name, "oneshot_spins")) { m->opt_oneshot_spins = std::max(1, value); return NVLLM_OK; }
+    if (!strcmp(name, "kv_v_bits")) {  // takes effect at the next kv_alloc
+        if (value != 16 && value != 24) return fail(m->ctx, NVLLM_EINVAL, "kv_v_bits is 16 or 24");
+        m->opt_kv_v_bits = value; return NVLLM_OK;
+    }
     if (!strcmp(name, "oneshot_skip_push")) { m->opt_oneshot_skip_push = std::max(0, value); return NVLLM_OK; }  // test hook
     if (!strcmp(name, "no_fused")) { m->opt_no_fused = value; return NVLLM_OK; }    // decode through the generic path
     if (!strcmp(name, "no_xpack")) { m->opt_no_xpack = value; return NVLLM_OK; }    // row-major activation planes

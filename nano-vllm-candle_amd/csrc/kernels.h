@@ -152,6 +152,7 @@ hipError_t launch_add_rmsnorm(const NormArgs& a, int rows, hipStream_t s);
 struct KvLayout {
     f16_bits* k = nullptr;  // [num_blocks][kv_l][16 tiles][hd/32][64 lanes][8] f16 (QK^T A-fragment packed)
     f16_bits* v = nullptr;  // [num_blocks][kv_l][8 tiles][hd/16][64 lanes][8] f16 (PV A-fragment packed)
+    uint8_t* vlo = nullptr; // optional 24-bit V: e5m2 rounding residual of every V element, same element order (1 byte each)
     int kv_l = 0, hd = 0;
 };
 struct QkvArgs {

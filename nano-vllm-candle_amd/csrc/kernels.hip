@@ -1161,10 +1161,14 @@ static RowDirShape rowdir_shape(int N, int K, int epi, int M) {
     } else if (epi == 1) {
         nt = (ntiles % 6 == 0 && tk == 2) ? 6 : 4;
         if (ntiles % 2 || nt * tk > 16) return none;
+        // one row block (<= 16 rows, e.g. batch 1): the grid is the n-groups alone, so fewer tiles per workgroup put the
+        // matrix on more CUs (0.6B gate/up: 64 -> 192 workgroups)
+        if (M <= 16 && ntiles / 2 <= 512) nt = 2;
     } else {
         nt = 4;
         if (nt * tk > 16) nt = 2;
         if (nt * tk > 16) return none;
+        if (M <= 16 && ntiles <= 512) nt = 1;  // as above (0.6B QKV: 64 -> 256 workgroups)
     }
     // weights are streamed once per row block: big matrices belong to the 64-row kernel
     if ((size_t)N * K * 2 >= ((size_t)24 << 20) && M > 16) return none;
@@ -1245,8 +1249,8 @@ template <int EPI>
 static hipError_t rowdir_dispatch(const RowDirShape& d, const RowParArgs& a, const PackedW& w, hipStream_t s) {
 #define NVLLM_RD(NT_, TK_) if (d.nt == NT_ && d.tk == TK_) return rowdir_launch_t<NT_, 16, TK_, EPI>(a, w, s);
     if constexpr (EPI == 0) { NVLLM_RD(1, 2) NVLLM_RD(1, 4) NVLLM_RD(1, 6) NVLLM_RD(1, 8) NVLLM_RD(2, 2) NVLLM_RD(2, 4) NVLLM_RD(2, 6) NVLLM_RD(4, 2) NVLLM_RD(4, 4) }
-    if constexpr (EPI == 1) { NVLLM_RD(6, 2) NVLLM_RD(4, 2) NVLLM_RD(4, 4) }
-    if constexpr (EPI == 2) { NVLLM_RD(4, 2) NVLLM_RD(4, 4) NVLLM_RD(2, 6) NVLLM_RD(2, 8) }
+    if constexpr (EPI == 1) { NVLLM_RD(6, 2) NVLLM_RD(4, 2) NVLLM_RD(4, 4) NVLLM_RD(2, 2) NVLLM_RD(2, 4) NVLLM_RD(2, 6) NVLLM_RD(2, 8) }
+    if constexpr (EPI == 2) { NVLLM_RD(4, 2) NVLLM_RD(4, 4) NVLLM_RD(2, 6) NVLLM_RD(2, 8) NVLLM_RD(1, 2) NVLLM_RD(1, 4) NVLLM_RD(1, 6) NVLLM_RD(1, 8) }
 #undef NVLLM_RD
     return hipErrorNotSupported;
 }
@@ -1528,9 +1532,11 @@ __global__ void __launch_bounds__(256) qk_norm_rope_kvwrite_kernel(QkvArgs a) {
     } else if (act) {  // v head: plain copy into the packed layout
         const int kh = hh - a.nh_l - kv_l;
         const int blk = a.block_tables[(size_t)a.slot[row] * a.max_blocks + (pos >> 8)];
-        _Float16* v = reinterpret_cast<_Float16*>(a.kv.v) + (size_t)(blk * kv_l + kh) * kBlockTokens * hd;
-        v[v_packed_offset(pos & 255, lane, hd)] = f16_sat(x1);
-        v[v_packed_offset(pos & 255, lane + half, hd)] = f16_sat(x2);
+        const size_t vo = (size_t)(blk * kv_l + kh) * kBlockTokens * hd;
+        _Float16* v = reinterpret_cast<_Float16*>(a.kv.v) + vo;
+        uint8_t* vlo = a.kv.vlo ? a.kv.vlo + vo : nullptr;
+        store_v24(v, vlo, v_packed_offset(pos & 255, lane, hd), x1);
+        store_v24(v, vlo, v_packed_offset(pos & 255, lane + half, hd), x2);
     }
 }
 
@@ -1555,8 +1561,8 @@ __global__ void __launch_bounds__(256) kv_write_plain_kernel(const float* __rest
         const int kh = i / kv.hd, d = i - kh * kv.hd;
         _Float16* kd = reinterpret_cast<_Float16*>(kv.k) + (size_t)(blk * kv.kv_l + kh) * kBlockTokens * kv.hd;
         kd[k_packed_offset(p & 255, d, kv.hd)] = f16_sat(k[(size_t)row * n + i]);
-        _Float16* vd = reinterpret_cast<_Float16*>(kv.v) + (size_t)(blk * kv.kv_l + kh) * kBlockTokens * kv.hd;
-        vd[v_packed_offset(p & 255, d, kv.hd)] = f16_sat(v[(size_t)row * n + i]);
+        const size_t vo = (size_t)(blk * kv.kv_l + kh) * kBlockTokens * kv.hd;
+        store_v24(reinterpret_cast<_Float16*>(kv.v) + vo, kv.vlo ? kv.vlo + vo : nullptr, v_packed_offset(p & 255, d, kv.hd), v[(size_t)row * n + i]);
     }
 }
 hipError_t launch_kv_write_plain(const float* k, const float* v, int rows, const int* pos, const int* slot,
@@ -1587,9 +1593,11 @@ hipError_t launch_kv_write_plain(const float* k, const float* v, int rows, const
 // wave (64 MB per launch at batch 64 beside 87 MB of K/V) that every wave then waited for at the combine barrier.
 __device__ uint4 g_attn_dummy_tile[1024];
 
-template <int HD, int QT, int NWV, bool FUSED>
-__global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(AttnArgs a) {
-    constexpr int DC = HD / 32, DT = HD / 16;
+// VLO: 24-bit V (KvLayout::vlo): every V fragment comes with 8 residual bytes per lane (a 512-byte wave-load); shifted into
+// the high byte they ARE the residuals' f16 bit patterns, which a second P.V MFMA adds (the kernel is HBM-bound: V bytes x1.5)
+template <int HD, int QT, int NWV, bool FUSED, bool VLO = false>
+__global__ void __launch_bounds__(NWV * 64, (QT == 1 && !VLO) ? 2 : 1) attn_paged_kernel(AttnArgs a) {
+    constexpr int DC = HD / 32, DT = HD / 16, DL = VLO ? DT : 1;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* ml = reinterpret_cast<float*>(smem_raw);                          // [NWV][QT][2][16]
     f32x4* obuf = reinterpret_cast<f32x4*>(smem_raw + NWV * QT * 2 * 16 * 4);  // [NWV][QT][DT][64]
@@ -1631,8 +1639,9 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
     const int* bt = a.block_tables + (size_t)slot * a.max_blocks;
     const _Float16* kbase = reinterpret_cast<const _Float16*>(a.kv.k);
     const _Float16* vbase = reinterpret_cast<const _Float16*>(a.kv.v);
+    const uint8_t* vlobase = a.kv.vlo;
     // one 32-token KV tile (tokens tb..tb+31 of block blk): 2*DC K fragments + DT V fragments, 16 KiB in 1 KiB wave-loads
-    auto load_tile_at = [&](int blk, int tb, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT]) {
+    auto load_tile_at = [&](int blk, int tb, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint2 (&vl)[DL]) {
         auto ld = [&](const _Float16* p) -> uint4 { return ld_stream16(p); };
         // packed K: the two 16-token tiles of this 32-token step are 2*DC contiguous 1 KiB fragments
         const _Float16* kb = kbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 4) * (DC * 512) + lane * 8;
@@ -1644,14 +1653,19 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
         const _Float16* vb = vbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 5) * (DT * 512);
 #pragma unroll
         for (int d = 0; d < DT; ++d) vf[d] = ld(vb + d * 512 + lane * 8);
+        if constexpr (VLO) {
+            const uint8_t* vlb = vlobase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 5) * (DT * 512) + lane * 8;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) vl[d] = ld_stream8(vlb + d * 512);
+        }
     };
-    auto load_tile = [&](int kt, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT]) {
+    auto load_tile = [&](int kt, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint2 (&vl)[DL]) {
         const int T0 = kt << 5;
-        load_tile_at(bt[T0 >> 8], T0 & 255, ka, kb2, vf);
+        load_tile_at(bt[T0 >> 8], T0 & 255, ka, kb2, vf, vl);
     };
     // tile kt if it exists (kt < t_end), else the shared dummy tile (same instruction stream, no K/V traffic)
     // avoid: a tile that must not be touched yet (see the fused prologue): its 32-token neighbour in the block is read instead
-    auto load_tile_or_dummy = [&](int kt, int t_end_, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], int avoid = -1) {
+    auto load_tile_or_dummy = [&](int kt, int t_end_, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint2 (&vl)[DL], int avoid = -1) {
         const bool real = kt < t_end_;
         const int T0 = min(kt, t_end_ - 1) << 5;
         const int blk = bt[T0 >> 8], tb = (T0 & 255) ^ (kt == avoid ? 32 : 0);
@@ -1665,9 +1679,16 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
         }
 #pragma unroll
         for (int d = 0; d < DT; ++d) vf[d] = ld_stream16(vb + d * 512);
+        if constexpr (VLO) {
+            const uint8_t* vlb = real ? vlobase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 5) * (DT * 512) + lane * 8
+                                      : reinterpret_cast<const uint8_t*>(g_attn_dummy_tile) + lane * 8;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) vl[d] = ld_stream8(vlb + d * 512);
+        }
     };
     // decode register sets (QT == 1): two 32-token tiles (32 KiB) of this wave are in flight at any time
     uint4 kaA[DC], kbA[DC], vfA[DT], kaB[DC], kbB[DC], vfB[DT];
+    uint2 vlA[DL], vlB[DL];
     f16x8 qh[QT][DC], ql[QT][DC];
     if constexpr (FUSED) {
         // Decode, fused prologue (replaces a separate launch): this workgroup is the only consumer of q heads
@@ -1722,7 +1743,7 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
         // tile (vmcnt retires in order) -- 16 KiB queued behind every other wave's first tile -- and the whole workgroup
         // waits for wave 0 at the barrier (in-kernel stamps: 7 us to the barrier, 3 us in it).  It loads its first tile
         // after the barrier instead.
-        if (wave != 0) load_tile_or_dummy(t_begin + wave, t_end, kaA, kbA, vfA, pos >> 5);
+        if (wave != 0) load_tile_or_dummy(t_begin + wave, t_end, kaA, kbA, vfA, vlA, pos >> 5);
         const float ri = a.rn.ssq ? 1.0f / sqrtf(wave_sum(ssq_g) * a.rn.inv_h + a.rn.eps) : 1.0f;
         for (int sl0 = 1; sl0 < a.n_slabs; sl0 += 2) {  // split-K slabs of the generic path's QKV GEMM, two per trip
             const size_t so0 = (size_t)sl0 * a.slab_stride, so1 = (size_t)min(sl0 + 1, a.n_slabs - 1) * a.slab_stride;
@@ -1759,9 +1780,11 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
                 _Float16* k = reinterpret_cast<_Float16*>(a.kv.k) + (size_t)(blk * kv_l + kh) * kBlockTokens * HD;
                 k[k_packed_offset(pos & 255, lane, HD)] = f16_sat(n1 * kc - n2 * ks);
                 k[k_packed_offset(pos & 255, lane + half, HD)] = f16_sat(n2 * kc + n1 * ks);
-                _Float16* v = reinterpret_cast<_Float16*>(a.kv.v) + (size_t)(blk * kv_l + kh) * kBlockTokens * HD;
-                v[v_packed_offset(pos & 255, lane, HD)] = f16_sat(vx1 * ri);
-                v[v_packed_offset(pos & 255, lane + half, HD)] = f16_sat(vx2 * ri);
+                const size_t vo = (size_t)(blk * kv_l + kh) * kBlockTokens * HD;
+                _Float16* v = reinterpret_cast<_Float16*>(a.kv.v) + vo;
+                uint8_t* vlo = VLO ? a.kv.vlo + vo : nullptr;
+                store_v24(v, vlo, v_packed_offset(pos & 255, lane, HD), vx1 * ri);
+                store_v24(v, vlo, v_packed_offset(pos & 255, lane + half, HD), vx2 * ri);
             }
             // make the new token visible to the other waves of THIS workgroup (same CU: write-through L1 -> L2)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1827,7 +1850,7 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
         for (int d = 0; d < DT; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    auto compute_tile = [&](int kt, const uint4 (&ka)[DC], const uint4 (&kb2)[DC], const uint4 (&vf)[DT]) {
+    auto compute_tile = [&](int kt, const uint4 (&ka)[DC], const uint4 (&kb2)[DC], const uint4 (&vf)[DT], const uint2 (&vl)[DL]) {
         const int T0 = kt << 5;
         const int tokA = T0 + grp * 4, tokB = T0 + 16 + grp * 4;
 #pragma unroll
@@ -1853,7 +1876,11 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
             const float mn = fmaxf(m[t], mt);
             const float alpha = exp2f(m[t] - mn);
             m[t] = mn;
-            f16x8 P;
+            // P as f16 hi + f16 lo (22 bits): a second P.V MFMA per fragment, free in an HBM-bound kernel.  A single f16 P
+            // carries 2^-12 of rounding noise per probability, whose realisation depends on how the context is walked
+            // (waves, split-KV parts): at 4097 tokens of context that alone moved the logits by 4e-4 over 8 layers
+            // (tools/dbg_alone_vs_batch.py).
+            f16x8 P, Pl;
             float ps = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1862,13 +1889,19 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
                 ps += pa + pb;
                 P[r] = (_Float16)pa;
                 P[4 + r] = (_Float16)pb;
+                Pl[r] = (_Float16)(pa - (float)P[r]);
+                Pl[4 + r] = (_Float16)(pb - (float)P[4 + r]);
             }
             lsum[t] = lsum[t] * alpha + ps;
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
                 f32x4 acc = o[t][d];
                 acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
-                o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vf[d]), P, acc, 0, 0, 0);
+                const f16x8 fv = __builtin_bit_cast(f16x8, vf[d]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fv, P, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fv, Pl, acc, 0, 0, 0);
+                if constexpr (VLO) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(e5m2x8_to_f16(vl[d]), P, acc, 0, 0, 0);
+                o[t][d] = acc;
             }
         }
     };
@@ -1885,35 +1918,36 @@ __global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(A
                     // no line of this tile can be in this CU's L1 (nobody touched it before the barrier); the agent-scope
                     // acquire (buffer_inv sc1) makes that independent of who else shares the CU.  Rare path: short contexts.
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    load_tile(kt, kaA, kbA, vfA);
+                    load_tile(kt, kaA, kbA, vfA, vlA);
                 } else if (wave == 0) {
-                    load_tile_or_dummy(kt, t_end, kaA, kbA, vfA);  // wave 0 skipped the early prefetch
+                    load_tile_or_dummy(kt, t_end, kaA, kbA, vfA, vlA);  // wave 0 skipped the early prefetch
                 }
-                load_tile_or_dummy(kt + NWV, t_end, kaB, kbB, vfB);
+                load_tile_or_dummy(kt + NWV, t_end, kaB, kbB, vfB, vlB);
             } else {
-                load_tile(min(kt, t_end - 1), kaA, kbA, vfA);
-                load_tile(min(kt + NWV, t_end - 1), kaB, kbB, vfB);
+                load_tile(min(kt, t_end - 1), kaA, kbA, vfA, vlA);
+                load_tile(min(kt + NWV, t_end - 1), kaB, kbB, vfB, vlB);
             }
             // refills past the end: the shared dummy tile (fused kernel: the one the model runs); the plain-q variant
             // (fine-seam op, tuning bench) keeps the clamped re-read -- the extra address selects would spill it
-            auto refill = [&](int kt_next, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT]) {
-                if constexpr (FUSED) load_tile_or_dummy(kt_next, t_end, ka, kb2, vf);
-                else load_tile(min(kt_next, t_end - 1), ka, kb2, vf);
+            auto refill = [&](int kt_next, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint2 (&vl)[DL]) {
+                if constexpr (FUSED) load_tile_or_dummy(kt_next, t_end, ka, kb2, vf, vl);
+                else load_tile(min(kt_next, t_end - 1), ka, kb2, vf, vl);
             };
             while (kt < t_end) {
-                compute_tile(kt, kaA, kbA, vfA);
-                refill(kt + 2 * NWV, kaA, kbA, vfA);
+                compute_tile(kt, kaA, kbA, vfA, vlA);
+                refill(kt + 2 * NWV, kaA, kbA, vfA, vlA);
                 kt += NWV;
                 if (kt >= t_end) break;
-                compute_tile(kt, kaB, kbB, vfB);
-                refill(kt + 2 * NWV, kaB, kbB, vfB);
+                compute_tile(kt, kaB, kbB, vfB, vlB);
+                refill(kt + 2 * NWV, kaB, kbB, vfB, vlB);
                 kt += NWV;
             }
         } else {
             uint4 ka[DC], kb2[DC], vf[DT];
+            uint2 vl[DL];
             for (int kt = t_begin + wave; kt < t_end; kt += NWV) {
-                load_tile(kt, ka, kb2, vf);
-                compute_tile(kt, ka, kb2, vf);
+                load_tile(kt, ka, kb2, vf, vl);
+                compute_tile(kt, ka, kb2, vf, vl);
             }
         }
     }
@@ -2162,7 +2196,7 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
         // compare, a select and an ldexp on top), v_max3 without the NaN canonicalisation fmaxf() pays per operand,
         // the causal mask only on tiles that reach past the wave's first row, and no rescale of O when no row's
         // maximum moved.
-        f16x8 P[QT];
+        f16x8 P[QT], Pl[QT];  // P as f16 hi + lo (see attn_paged_kernel): the prompt's own K/V-dependent rows keep 22 bits too
         float alpha[QT];
         auto softmax = [&](auto masked_c) {
             constexpr bool MASKED = decltype(masked_c)::value;
@@ -2193,6 +2227,8 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
                     ps += pa + pb;
                     P[t][r] = (_Float16)pa;
                     P[t][4 + r] = (_Float16)pb;
+                    Pl[t][r] = (_Float16)(pa - (float)P[t][r]);
+                    Pl[t][4 + r] = (_Float16)(pb - (float)P[t][4 + r]);
                 }
                 lsum[t] = lsum[t] * alpha[t] + ps;
             }
@@ -2214,7 +2250,10 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_kernel(AttnArgs a) {
         for (int d = 0; d < DT; ++d) {
             const f16x8 fv = __builtin_bit_cast(f16x8, lds[(size_t)(buf * TILE_FRAGS + 2 * DC + d) * 64 + lane]);
 #pragma unroll
-            for (int t = 0; t < QT; ++t) o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fv, P[t], o[t][d], 0, 0, 0);
+            for (int t = 0; t < QT; ++t) {
+                o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fv, P[t], o[t][d], 0, 0, 0);
+                o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fv, Pl[t], o[t][d], 0, 0, 0);
+            }
         }
     }
     NVLLM_STAMP(a, 2);
@@ -2283,20 +2322,28 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(AttnArgs a, int rows)
     }
 }
 
-template <int HD, int QT, int NWV, bool FUSED>
-static hipError_t attn_launch_t(const AttnArgs& a, int n_tiles, int grid_z, hipStream_t s) {
+template <int HD, int QT, int NWV, bool FUSED, bool VLO>
+static hipError_t attn_launch_v(const AttnArgs& a, int n_tiles, int grid_z, hipStream_t s) {
     constexpr int DT = HD / 16;
     const size_t lds = (size_t)NWV * QT * 2 * 16 * 4 + (size_t)NWV * QT * DT * 64 * 16;
     static std::atomic<uint64_t> lds_set{0};
-    ensure_dyn_lds(reinterpret_cast<const void*>(attn_paged_kernel<HD, QT, NWV, FUSED>), lds, lds_set);
+    ensure_dyn_lds(reinterpret_cast<const void*>(attn_paged_kernel<HD, QT, NWV, FUSED, VLO>), lds, lds_set);
     dim3 grid(n_tiles, a.kv.kv_l, grid_z);
-    attn_paged_kernel<HD, QT, NWV, FUSED><<<grid, NWV * 64, lds, s>>>(a);
+    attn_paged_kernel<HD, QT, NWV, FUSED, VLO><<<grid, NWV * 64, lds, s>>>(a);
     return hipGetLastError();
+}
+template <int HD, int QT, int NWV, bool FUSED>
+static hipError_t attn_launch_t(const AttnArgs& a, int n_tiles, int grid_z, hipStream_t s) {
+    // 24-bit V (KvLayout::vlo) is served for head_dim 128 only (every Qwen3 size); the pool refuses it otherwise
+    if constexpr (HD == 128) { if (a.kv.vlo) return attn_launch_v<HD, QT, NWV, FUSED, true>(a, n_tiles, grid_z, s); }
+    else if (a.kv.vlo) return hipErrorNotSupported;
+    return attn_launch_v<HD, QT, NWV, FUSED, false>(a, n_tiles, grid_z, s);
 }
 
 // prefill: n_tiles (a multiple of 4: every sequence's tile list padded with empty tiles) q-tiles of 2 sub-tiles each
 hipError_t launch_attn_prefill(const AttnArgs& a, int n_tiles, hipStream_t s) {
     if (n_tiles <= 0) return hipSuccess;
+    if (a.kv.vlo) return hipErrorNotSupported;  // 24-bit V: the caller runs prompt chunks through attn_paged_kernel<.., 2, ..>
     if (n_tiles % 4 || a.gqa < 1 || a.gqa > 16 || (a.kv.hd != 128 && a.kv.hd != 64)) return hipErrorInvalidValue;
     dim3 grid((n_tiles / 4) * a.kv.kv_l);
     if (a.kv.hd == 128) {

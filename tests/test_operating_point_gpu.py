@@ -29,14 +29,14 @@ def ctx(pkg):
     return layers.default_context()
 
 
-def check_rows(tag, ids, lg, rid, rlg):
+def check_rows(tag, ids, lg, rid, rlg, tol=LOGITS_TOL):
     """rows of GPU logits vs oracle rows: error < 1e-3 (north_star), ids equal where the margin is clear"""
     errs = [rel_err(g, r) for g, r in zip(lg, rlg)]
     srt = np.sort(rlg, axis=1)
-    clear = (srt[:, -1] - srt[:, -2]) / np.abs(rlg).max(axis=1) > MARGIN
-    print(f"[parity] {tag}: worst row error {max(errs):.3e} (tolerance {LOGITS_TOL:g}), "
+    clear = (srt[:, -1] - srt[:, -2]) / np.abs(rlg).max(axis=1) > max(MARGIN, 2 * tol)
+    print(f"[parity] {tag}: worst row error {max(errs):.3e} (tolerance {tol:g}), "
           f"{int(clear.sum())}/{len(errs)} rows with a clear top-2 margin")
-    assert max(errs) < LOGITS_TOL, (tag, errs)
+    assert max(errs) < tol, (tag, errs)
     assert (np.asarray(ids) == np.asarray(rid))[clear].all(), (tag, ids, rid)
     return max(errs)
 
@@ -401,7 +401,7 @@ def test_8b_full_size_batch256_context4096_properties(pkg, ctx):
     cfg = pkg.Qwen3Config.qwen3_8b()
     B, T = 256, 4096
     m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
-    m.kv_alloc(num_blocks=B * 17 + 40, max_seqs=B, max_batched_tokens=4096)
+    m.kv_alloc(num_blocks=B * 17 + 40, max_seqs=B + 2, max_batched_tokens=4096)
     rng = np.random.default_rng(8)
     prompts = [rng.integers(0, cfg.vocab_size, T, dtype=np.uint32).tolist() for _ in range(B)]
     sids = list(range(B))

@@ -13,15 +13,27 @@ os.environ.setdefault("NVLLM_LIB", "libnvllm_amd_stamps.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nano_vllm_candle_amd as pkg  # noqa: E402
 
+import argparse  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--prompt-min", type=int, default=64)
+ap.add_argument("--prompt-max", type=int, default=512)
+ap.add_argument("--option", action="append", default=[])
+args = ap.parse_args()
+B = args.batch
 L = pkg._lib.lib()
 ctx = pkg.Context(0)
 cfg = pkg.Qwen3Config.qwen3_0_6b()
 m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx)
+for o in args.option:
+    name, _, val = o.partition("=")
+    m.set_option(name, int(val or 1))
 rng = np.random.default_rng(0)
-lens = rng.integers(64, 513, size=64)
+lens = rng.integers(args.prompt_min, args.prompt_max + 1, size=B)
 prompts = [rng.integers(0, cfg.vocab_size, size=int(n), dtype=np.uint32).tolist() for n in lens]
-m.kv_alloc(num_blocks=64 * 3 + 2, max_seqs=64, max_batched_tokens=4096)
-m.step(list(range(64)), prompts, True)
+m.kv_alloc(num_blocks=B * 3 + 2, max_seqs=B, max_batched_tokens=4096)
+m.step(list(range(B)), prompts, True)
 for _ in range(40):
     m.decode_next()
 pkg._lib.check(L.nvllm_debug_stamps(m.h, 1), ctx.h)
@@ -50,7 +62,7 @@ for layer in (10, 11, 12):
         print(f"layer {layer} {name:8s}: {int(wg.sum()):4d} WGs, kernel {(k4 - k0) / 100.0:6.2f} us (gap before {gap:5.2f} us), start skew {(t0.max() - k0) / 100.0:5.2f}, "
               f"per-WG lifetime median {np.median(t4 - t0) / 100.0:5.2f} max {(t4 - t0).max() / 100.0:5.2f}; "
               "segments median/max us: " + "  ".join(f"{i}->{i + 1} {a_:.2f}/{b_:.2f}" for i, (a_, b_) in enumerate(seg)))
-        if name == "attn":
+        if name == "attn" and B == 64:
             # workgroup (x = rank in the longest-first order, y = kv head): lifetime vs context length
             order = np.argsort(-ctx_lens, kind="stable")
             life = np.zeros(64)
