@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--prefill-only", action="store_true",
                     help="time the prefill of the batch (cold call + warmed repeats) and stop: the MFMA-side profile run")
     ap.add_argument("--prefill-reps", type=int, default=3)
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the rocprofv3 --pmc FETCH_SIZE child pass that fills roofline.traffic (N = 1 only; ~20 s)")
     ap.add_argument("--profile-meta", action="store_true",
                     help="add `all_decode_steps` to the line (tools/summarize_prof.py: bytes per launch averaged over EVERY decode step "
                          "of the process, what a rocprofv3 --stats average covers); off by default: one byte count per kernel in the line")
@@ -269,6 +271,53 @@ def run_tp_projection_point(pkg, a, tp):
     model.close()
     ctx.close()
     return res
+
+
+def live_traffic(a, dom_kernel):
+    """roofline.traffic measured in THIS invocation: the same decode workload once more in a child process under
+    `rocprofv3 --pmc FETCH_SIZE` (counters in a pass of their own, as /opt/skills/guides/MI355X_MICROARCH.md prescribes:
+    FETCH_SIZE is in KB and reads half the bytes of wide streaming loads on gfx950 -> x 1024 x 2).  The child runs the same
+    steps, so the average is over the same launches as its own algorithmic byte count.  Any failure -> None + the reason."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR")):
+        return None, "already running under a profiler (no nested counter pass)"
+    tmp = tempfile.mkdtemp(prefix="nvllm_pmc_", dir="/tmp")
+    cmd = ["rocprofv3", "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "r", "--",
+           sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(a.steps), "--warmup", str(a.warmup),
+           "--model", a.model, "--batch", str(a.batch), "--prompt-min", str(a.prompt_min), "--prompt-max", str(a.prompt_max),
+           "--seed", str(a.seed), "--profile-steps", str(a.profile_steps), "--no-cpu-baseline", "--skip-tp-leg", "--no-live-traffic",
+           "--profile-meta"] + [x for o in a.option for x in ("--option", o)]
+    try:
+        cp = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+        line = [l for l in cp.stdout.splitlines() if l.startswith('{"metric"')]
+        files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+        if cp.returncode != 0 or not line or not files:
+            return None, f"counter pass failed (exit {cp.returncode}): " + (cp.stderr.strip().splitlines() or ["no output"])[-1][:200]
+        child = json.loads(line[-1])
+        n, tot = 0, 0.0
+        with open(files[0]) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") == "FETCH_SIZE" and dom_kernel in row["Kernel_Name"].replace("nvllm::", ""):
+                    n += 1
+                    tot += float(row["Counter_Value"])
+        if n == 0:
+            return None, f"no dispatch of {dom_kernel} in the counter pass"
+        fetch = 2.0 * 1024.0 * tot / n
+        alg = child.get("all_decode_steps", {}).get("attn_algorithmic_bytes_per_launch") if dom_kernel.startswith("attn_paged") else None
+        return {"bytes_per_launch": fetch, "launches": n, "over_algorithmic_of_that_pass": (fetch / alg) if alg else None,
+                "how": "child pass: rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py <same workload>; mean FETCH_SIZE [KB] x 1024 x 2 "
+                       "(gfx950 wide-stream correction)"}, None
+    except Exception as e:  # noqa: BLE001
+        return None, repr(e)[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -491,6 +540,13 @@ def main():
             roof["traffic_from_profile"] = {"file": "profiles/" + pmc_path,
                                             "hbm_fetch_over_algorithmic": pmc["fetch_bytes_per_launch"] / pmc["algorithmic_bytes_per_launch"]}
             break
+    if rank == 0 and world == 1 and not a.no_live_traffic and dom in ("attn", "lm_head"):
+        tr, why = live_traffic(a, dom_name)
+        if tr:
+            roof["traffic"] = tr["bytes_per_launch"]
+            roof["traffic_detail"] = {k: v for k, v in tr.items() if k != "bytes_per_launch"}
+        else:
+            roof["traffic_unavailable"] = why
     if dom_bytes is not None:
         roof["achieved"] = dom_bytes / (launch_us * 1e-6) / 1e9
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS

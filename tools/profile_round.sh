@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 D="--gpus 1 --steps 20 --warmup 5"
 timeout -k 10 700 python3 $R/bench.py $D > $R/gpurun_out/bench_$TAG.log 2>&1 || exit 1
 tail -1 $R/gpurun_out/bench_$TAG.log | cut -c1-200
-B="python3 $R/bench.py --no-cpu-baseline --skip-tp-leg --profile-meta"
+B="python3 $R/bench.py --no-cpu-baseline --skip-tp-leg --profile-meta --no-live-traffic"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o r -- $B $D > $R/gpurun_out/prof_$TAG.log 2>&1 || exit 2
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$TAG -o r -- $B $D > $R/gpurun_out/pmc_$TAG.log 2>&1 || exit 3
 # prefill (MFMA side): kernel stats of a prefill-only run, then matrix-core counters in their own pass
