@@ -1101,7 +1101,9 @@ static bool fused_plan(const nvllm_model* m, int R, FusedPlan& p) {
     else p.gu = G_GENERIC;  // generic kernel with the SwiGLU epilogue (no K split)
     const bool no_xpack = m->opt_no_xpack != 0;
     auto takes_packed = [&](int kind, int N, int K, int epi) { return kind == G_STREAM || (kind == G_ROW && gemm_rowdir_ok(N, K, epi, R)); };
-    p.packed = !no_xpack && m->I_l % 32 == 0 && takes_packed(p.qkv, NQ, H, 2) && takes_packed(p.o, H, KO, tp ? 2 : 0) &&
+    // fewer than 16 rows: a fragment-order plane is 15/16 padding (a 1-row step would load 1 KiB per k-tile where a
+    // row-major plane serves 64 bytes to all 16 lanes): batch 1 measured 960 -> 1017 tokens/s with row-major planes
+    p.packed = !no_xpack && R >= 16 && m->I_l % 32 == 0 && takes_packed(p.qkv, NQ, H, 2) && takes_packed(p.o, H, KO, tp ? 2 : 0) &&
                takes_packed(p.gu, I2, H, 1) && takes_packed(p.down, H, m->I_l, tp ? 2 : 0);
     return true;
 }
@@ -1484,7 +1486,9 @@ static void set_attn_split(nvllm_model* m, int n_seqs, int max_len) {
     const int tiles = (max_len + 31) / 32;
     const int base_wgs = std::max(1, n_seqs * m->kv_l);
     int want = std::min(kAttnMaxParts, std::max(1, 512 / base_wgs));
-    if (tiles <= 8) want = 1;  // <= 256 tokens: four waves hold the whole context in one round; a combine launch costs more
+    // <= 256 tokens: four waves hold the whole context in one round; <= 512: two more rounds of the loop (~2.6 us) still cost
+    // less than the combine launch and its boundary (4.7 + 1.4 us, batch-1 profile)
+    if (tiles <= 16) want = 1;
     int part = std::max(4, (tiles + want - 1) / want);  // >= 128 tokens per workgroup
     m->attn_part_tiles = part;
     m->attn_parts_max = (tiles + part - 1) / part;

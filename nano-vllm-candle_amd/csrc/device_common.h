@@ -27,17 +27,13 @@ __device__ __forceinline__ void split_bf16(float x, uint16_t& hi, uint16_t& lo) 
 __device__ __forceinline__ _Float16 f16_sat(float x) { return (_Float16)fminf(fmaxf(x, -65504.f), 65504.f); }
 
 // 24-bit V (opt-in): beside the f16 value the cache keeps the rounding residual r = x - f16(x) as the TOP BYTE
+// of f16(r) -- a bf8 / e5m2 number (sign, 5 exponent bits, 2 mantissa bits), rounded to nearest even.  |r| <= ulp/2, so the
+// pair carries 13..14 significant bits; the attention kernels feed the bytes to a bf8 MFMA as they are.
+
+// 24-bit V (opt-in): beside the f16 value the cache keeps the rounding residual r = x - f16(x) as the TOP BYTE
 // of f16(r) -- an e5m2 number (sign, 5 exponent bits, 2 mantissa bits), rounded to nearest even.  |r| <= ulp/2, so the pair
 // carries 13..14 significant bits, and the reader rebuilds r's f16 by a byte shift (no arithmetic).
-__device__ __forceinline__ void store_v24(_Float16* v, uint8_t* vlo, size_t off, float x) {
-    const _Float16 h = f16_sat(x);
-    v[off] = h;
-    if (vlo) {
-        const float xc = fminf(fmaxf(x, -65504.f), 65504.f);
-        const uint32_t b = __builtin_bit_cast(uint16_t, (_Float16)(xc - (float)h));
-        vlo[off] = (uint8_t)((b + 0x7Fu + ((b >> 8) & 1u)) >> 8);
-    }
-}
+__device__ __forceinline__ void store_v24(_Float16* v, uint8_t* vlo, int t_in_block, int d, int hd, float x);
 
 // max of three without the canonicalising v_max_f32 x, x that fmaxf() adds per operand (operands here are MFMA results
 // and finite constants: no signalling NaN to quiet)
@@ -58,19 +54,6 @@ __device__ __forceinline__ uint4 ld_stream16(const void* p) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
     return make_uint4(v[0], v[1], v[2], v[3]);
-}
-
-__device__ __forceinline__ uint2 ld_stream8(const void* p) {
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
-    return make_uint2(v[0], v[1]);
-}
-// 8 e5m2 bytes -> 8 f16 (an e5m2 number is the top byte of the f16 with the same value): v_perm_b32 moves byte j into the
-// high byte of half j; selector 0x0c yields 0x00
-__device__ __forceinline__ f16x8 e5m2x8_to_f16(uint2 b) {
-    const uint4 r = make_uint4(__builtin_amdgcn_perm(b.x, b.x, 0x010c000cu), __builtin_amdgcn_perm(b.x, b.x, 0x030c020cu),
-                               __builtin_amdgcn_perm(b.y, b.y, 0x010c000cu), __builtin_amdgcn_perm(b.y, b.y, 0x030c020cu));
-    return __builtin_bit_cast(f16x8, r);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -150,6 +133,25 @@ __device__ __forceinline__ size_t v_packed_offset(int t_in_block, int d, int hd)
     const int tile = t_in_block >> 5, tt = t_in_block & 31;
     const int g = (tt & 15) >> 2, j = ((tt >> 4) << 2) | (tt & 3);
     return ((size_t)(tile * (hd >> 4) + (d >> 4)) * 64 + (g << 4) + (d & 15)) * 8 + j;
+}
+
+// 24-bit V: the residual bytes of TWO neighbouring PV fragments (features 32p..32p+15 and 32p+16..32p+31) share one 16-byte
+// lane slot, [8 bytes of the even fragment][8 of the odd one], so the attention kernels fetch them with full 1 KiB wave-loads
+// (512-byte loads cost the memory pipe as much per instruction as 1 KiB ones: measured +48 % kernel time for +25 % bytes).
+// Byte offset inside one (block, kv head) slab of kBlockTokens x hd bytes:
+__device__ __forceinline__ size_t vlo_packed_offset(int t_in_block, int d, int hd) {
+    const int tile = t_in_block >> 5, tt = t_in_block & 31;
+    const int g = (tt & 15) >> 2, j = ((tt >> 4) << 2) | (tt & 3);
+    return ((size_t)(tile * (hd >> 5) + (d >> 5)) * 64 + (g << 4) + (d & 15)) * 16 + (size_t)(((d >> 4) & 1) << 3) + j;
+}
+__device__ __forceinline__ void store_v24(_Float16* v, uint8_t* vlo, int t_in_block, int d, int hd, float x) {
+    const _Float16 h = f16_sat(x);
+    v[v_packed_offset(t_in_block, d, hd)] = h;
+    if (vlo) {
+        const float xc = fminf(fmaxf(x, -65504.f), 65504.f);
+        const uint32_t b = __builtin_bit_cast(uint16_t, (_Float16)(xc - (float)h));
+        vlo[vlo_packed_offset(t_in_block, d, hd)] = (uint8_t)((b + 0x7Fu + ((b >> 8) & 1u)) >> 8);
+    }
 }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;

@@ -1535,8 +1535,8 @@ __global__ void __launch_bounds__(256) qk_norm_rope_kvwrite_kernel(QkvArgs a) {
         const size_t vo = (size_t)(blk * kv_l + kh) * kBlockTokens * hd;
         _Float16* v = reinterpret_cast<_Float16*>(a.kv.v) + vo;
         uint8_t* vlo = a.kv.vlo ? a.kv.vlo + vo : nullptr;
-        store_v24(v, vlo, v_packed_offset(pos & 255, lane, hd), x1);
-        store_v24(v, vlo, v_packed_offset(pos & 255, lane + half, hd), x2);
+        store_v24(v, vlo, pos & 255, lane, hd, x1);
+        store_v24(v, vlo, pos & 255, lane + half, hd, x2);
     }
 }
 
@@ -1562,7 +1562,7 @@ __global__ void __launch_bounds__(256) kv_write_plain_kernel(const float* __rest
         _Float16* kd = reinterpret_cast<_Float16*>(kv.k) + (size_t)(blk * kv.kv_l + kh) * kBlockTokens * kv.hd;
         kd[k_packed_offset(p & 255, d, kv.hd)] = f16_sat(k[(size_t)row * n + i]);
         const size_t vo = (size_t)(blk * kv.kv_l + kh) * kBlockTokens * kv.hd;
-        store_v24(reinterpret_cast<_Float16*>(kv.v) + vo, kv.vlo ? kv.vlo + vo : nullptr, v_packed_offset(p & 255, d, kv.hd), v[(size_t)row * n + i]);
+        store_v24(reinterpret_cast<_Float16*>(kv.v) + vo, kv.vlo ? kv.vlo + vo : nullptr, p & 255, d, kv.hd, v[(size_t)row * n + i]);
     }
 }
 hipError_t launch_kv_write_plain(const float* k, const float* v, int rows, const int* pos, const int* slot,
@@ -1596,8 +1596,8 @@ __device__ uint4 g_attn_dummy_tile[1024];
 // VLO: 24-bit V (KvLayout::vlo): every V fragment comes with 8 residual bytes per lane (a 512-byte wave-load); shifted into
 // the high byte they ARE the residuals' f16 bit patterns, which a second P.V MFMA adds (the kernel is HBM-bound: V bytes x1.5)
 template <int HD, int QT, int NWV, bool FUSED, bool VLO = false>
-__global__ void __launch_bounds__(NWV * 64, (QT == 1 && !VLO) ? 2 : 1) attn_paged_kernel(AttnArgs a) {
-    constexpr int DC = HD / 32, DT = HD / 16, DL = VLO ? DT : 1;
+__global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1) attn_paged_kernel(AttnArgs a) {
+    constexpr int DC = HD / 32, DT = HD / 16, DL = VLO ? DT / 2 : 1;  // DL: 1 KiB residual fragments per tile (two PV fragments each)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* ml = reinterpret_cast<float*>(smem_raw);                          // [NWV][QT][2][16]
     f32x4* obuf = reinterpret_cast<f32x4*>(smem_raw + NWV * QT * 2 * 16 * 4);  // [NWV][QT][DT][64]
@@ -1641,7 +1641,7 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !VLO) ? 2 : 1) attn_page
     const _Float16* vbase = reinterpret_cast<const _Float16*>(a.kv.v);
     const uint8_t* vlobase = a.kv.vlo;
     // one 32-token KV tile (tokens tb..tb+31 of block blk): 2*DC K fragments + DT V fragments, 16 KiB in 1 KiB wave-loads
-    auto load_tile_at = [&](int blk, int tb, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint2 (&vl)[DL]) {
+    auto load_tile_at = [&](int blk, int tb, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint4 (&vl)[DL]) {
         auto ld = [&](const _Float16* p) -> uint4 { return ld_stream16(p); };
         // packed K: the two 16-token tiles of this 32-token step are 2*DC contiguous 1 KiB fragments
         const _Float16* kb = kbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 4) * (DC * 512) + lane * 8;
@@ -1654,18 +1654,18 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !VLO) ? 2 : 1) attn_page
 #pragma unroll
         for (int d = 0; d < DT; ++d) vf[d] = ld(vb + d * 512 + lane * 8);
         if constexpr (VLO) {
-            const uint8_t* vlb = vlobase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 5) * (DT * 512) + lane * 8;
+            const uint8_t* vlb = vlobase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 5) * (DL * 1024) + lane * 16;
 #pragma unroll
-            for (int d = 0; d < DT; ++d) vl[d] = ld_stream8(vlb + d * 512);
+            for (int d = 0; d < DL; ++d) vl[d] = ld_stream16(vlb + d * 1024);
         }
     };
-    auto load_tile = [&](int kt, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint2 (&vl)[DL]) {
+    auto load_tile = [&](int kt, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint4 (&vl)[DL]) {
         const int T0 = kt << 5;
         load_tile_at(bt[T0 >> 8], T0 & 255, ka, kb2, vf, vl);
     };
     // tile kt if it exists (kt < t_end), else the shared dummy tile (same instruction stream, no K/V traffic)
     // avoid: a tile that must not be touched yet (see the fused prologue): its 32-token neighbour in the block is read instead
-    auto load_tile_or_dummy = [&](int kt, int t_end_, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint2 (&vl)[DL], int avoid = -1) {
+    auto load_tile_or_dummy = [&](int kt, int t_end_, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint4 (&vl)[DL], int avoid = -1) {
         const bool real = kt < t_end_;
         const int T0 = min(kt, t_end_ - 1) << 5;
         const int blk = bt[T0 >> 8], tb = (T0 & 255) ^ (kt == avoid ? 32 : 0);
@@ -1680,15 +1680,15 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !VLO) ? 2 : 1) attn_page
 #pragma unroll
         for (int d = 0; d < DT; ++d) vf[d] = ld_stream16(vb + d * 512);
         if constexpr (VLO) {
-            const uint8_t* vlb = real ? vlobase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 5) * (DT * 512) + lane * 8
-                                      : reinterpret_cast<const uint8_t*>(g_attn_dummy_tile) + lane * 8;
+            const uint8_t* vlb = real ? vlobase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 5) * (DL * 1024) + lane * 16
+                                      : reinterpret_cast<const uint8_t*>(g_attn_dummy_tile) + lane * 16;
 #pragma unroll
-            for (int d = 0; d < DT; ++d) vl[d] = ld_stream8(vlb + d * 512);
+            for (int d = 0; d < DL; ++d) vl[d] = ld_stream16(vlb + d * 1024);
         }
     };
     // decode register sets (QT == 1): two 32-token tiles (32 KiB) of this wave are in flight at any time
     uint4 kaA[DC], kbA[DC], vfA[DT], kaB[DC], kbB[DC], vfB[DT];
-    uint2 vlA[DL], vlB[DL];
+    uint4 vlA[DL], vlB[DL];
     f16x8 qh[QT][DC], ql[QT][DC];
     if constexpr (FUSED) {
         // Decode, fused prologue (replaces a separate launch): this workgroup is the only consumer of q heads
@@ -1783,8 +1783,8 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !VLO) ? 2 : 1) attn_page
                 const size_t vo = (size_t)(blk * kv_l + kh) * kBlockTokens * HD;
                 _Float16* v = reinterpret_cast<_Float16*>(a.kv.v) + vo;
                 uint8_t* vlo = VLO ? a.kv.vlo + vo : nullptr;
-                store_v24(v, vlo, v_packed_offset(pos & 255, lane, HD), vx1 * ri);
-                store_v24(v, vlo, v_packed_offset(pos & 255, lane + half, HD), vx2 * ri);
+                store_v24(v, vlo, pos & 255, lane, HD, vx1 * ri);
+                store_v24(v, vlo, pos & 255, lane + half, HD, vx2 * ri);
             }
             // make the new token visible to the other waves of THIS workgroup (same CU: write-through L1 -> L2)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1850,7 +1850,7 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !VLO) ? 2 : 1) attn_page
         for (int d = 0; d < DT; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    auto compute_tile = [&](int kt, const uint4 (&ka)[DC], const uint4 (&kb2)[DC], const uint4 (&vf)[DT], const uint2 (&vl)[DL]) {
+    auto compute_tile = [&](int kt, const uint4 (&ka)[DC], const uint4 (&kb2)[DC], const uint4 (&vf)[DT], const uint4 (&vl)[DL]) {
         const int T0 = kt << 5;
         const int tokA = T0 + grp * 4, tokB = T0 + 16 + grp * 4;
 #pragma unroll
@@ -1893,6 +1893,15 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !VLO) ? 2 : 1) attn_page
                 Pl[4 + r] = (_Float16)(pb - (float)P[4 + r]);
             }
             lsum[t] = lsum[t] * alpha + ps;
+            [[maybe_unused]] long P8 = 0;
+            if constexpr (VLO) {
+                int w0 = 0, w1 = 0;
+                w0 = __builtin_amdgcn_cvt_pk_bf8_f32((float)P[0], (float)P[1], w0, false);
+                w0 = __builtin_amdgcn_cvt_pk_bf8_f32((float)P[2], (float)P[3], w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_bf8_f32((float)P[4], (float)P[5], w1, false);
+                w1 = __builtin_amdgcn_cvt_pk_bf8_f32((float)P[6], (float)P[7], w1, true);
+                P8 = (long)(((unsigned long long)(unsigned)w1 << 32) | (unsigned)w0);
+            }
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
                 f32x4 acc = o[t][d];
@@ -1900,7 +1909,13 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !VLO) ? 2 : 1) attn_page
                 const f16x8 fv = __builtin_bit_cast(f16x8, vf[d]);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fv, P, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fv, Pl, acc, 0, 0, 0);
-                if constexpr (VLO) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(e5m2x8_to_f16(vl[d]), P, acc, 0, 0, 0);
+                // the residual bytes ARE bf8 (e5m2) numbers: one fp8-family MFMA against P in bf8 adds the 2^-12-sized term
+                // (P's two mantissa bits leave it 12 % accurate: 2^-15 of V) without unpacking anything
+                if constexpr (VLO) {
+                    const uint4 pr = vl[d >> 1];
+                    const unsigned long long lo8 = (d & 1) ? ((unsigned long long)pr.w << 32) | pr.z : ((unsigned long long)pr.y << 32) | pr.x;
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8((long)lo8, P8, acc, 0, 0, 0);
+                }
                 o[t][d] = acc;
             }
         }
@@ -1929,7 +1944,7 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !VLO) ? 2 : 1) attn_page
             }
             // refills past the end: the shared dummy tile (fused kernel: the one the model runs); the plain-q variant
             // (fine-seam op, tuning bench) keeps the clamped re-read -- the extra address selects would spill it
-            auto refill = [&](int kt_next, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint2 (&vl)[DL]) {
+            auto refill = [&](int kt_next, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint4 (&vl)[DL]) {
                 if constexpr (FUSED) load_tile_or_dummy(kt_next, t_end, ka, kb2, vf, vl);
                 else load_tile(min(kt_next, t_end - 1), ka, kb2, vf, vl);
             };
@@ -1944,7 +1959,7 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !VLO) ? 2 : 1) attn_page
             }
         } else {
             uint4 ka[DC], kb2[DC], vf[DT];
-            uint2 vl[DL];
+            uint4 vl[DL];
             for (int kt = t_begin + wave; kt < t_end; kt += NWV) {
                 load_tile(kt, ka, kb2, vf, vl);
                 compute_tile(kt, ka, kb2, vf, vl);
