@@ -1,5 +1,6 @@
 """Time the decode attention kernel alone for several context-length distributions / split sizes.
-NVLLM_ATTN_ROT=n cycles n cache copies (default 8: cold HBM every launch); NVLLM_ATTN_WAVES=4|8."""
+The bench cycles through 8 cache copies (cold HBM every launch, like the model's per-layer caches).  PARTS=0,256 (this
+script's own variable): split sizes in tokens to try."""
 import ctypes as C
 import os
 import sys
@@ -32,4 +33,4 @@ for name, lens in cases.items():
     for part in parts:
         r = run(lens, part)
         if r:
-            print(f"waves={os.environ.get('NVLLM_ATTN_WAVES','4')} rot={os.environ.get('NVLLM_ATTN_ROT','8')} {name:22s} part={part:4d}: {r[0]:8.2f} us  {r[1]:7.1f} GB/s", flush=True)
+            print(f"{name:22s} part={part:4d}: {r[0]:8.2f} us  {r[1]:7.1f} GB/s", flush=True)
