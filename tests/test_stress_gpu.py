@@ -250,3 +250,59 @@ def test_32b_layer_shapes_heavy_tp8_shards_vs_oracle(pkg, oracle, oneshot, v_bit
                        tol_for(v_bits))
         for s, t in zip(ref, rid):
             s.append(int(t))
+
+
+def test_24_bit_v_cache_paths_on_a_small_model(pkg, ctx, oracle):
+    # every writer and reader of the 24-bit V cache on a small head_dim-128 model, benign weights: a ragged batch whose prompts
+    # go through the row kernel (qk_norm_rope_kvwrite) + attn_paged_kernel<.., 2, .., VLO>, decode through the fused
+    # prologue's store_v24 + the VLO decode kernel, one sequence growing across a 256-token block boundary, a long one alone
+    # (split-KV + combine), slots freed and reused, the device-feedback decode; then the pool goes back to 16 bits.
+    # The 24-bit pool must never be WORSE than the 16-bit one beyond noise and must report its bytes; head_dim 64 refuses it.
+    from tests.util import LOGITS_TOL, rel_err
+
+    cfg = pkg.Qwen3Config.tiny(hidden_size=256, head_dim=128, num_attention_heads=4, num_key_value_heads=2, intermediate_size=512,
+                               num_hidden_layers=3, vocab_size=1024)
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(3)
+    rng = np.random.default_rng(24)
+    worst = {}
+    for bits in (24, 16):
+        m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 3, ctx)
+        m.set_option("kv_v_bits", bits)
+        m.kv_alloc(num_blocks=12, max_seqs=4, max_batched_tokens=128)
+        assert m.kv_bytes_per_token == cfg.num_key_value_heads * cfg.head_dim * (5 if bits == 24 else 4) * cfg.num_hidden_layers
+        rng = np.random.default_rng(24)
+        seqs = [rng.integers(0, cfg.vocab_size, n).tolist() for n in (250, 37, 5)]  # 250 -> crosses 256 while decoding
+        sids = [0, 1, 2]
+        w = 0.0
+        for step in range(10):
+            ids, lg = m.step(sids, seqs, step == 0, want_logits=True)
+            rid, rlg = om.run_greedy(seqs)
+            w = max(w, max(rel_err(a, b) for a, b in zip(lg, rlg)))
+            assert ids.tolist() == rid.tolist(), (bits, step)
+            for s, t in zip(seqs, rid):
+                s.append(int(t))
+        nxt = m.decode_next()[:3]
+        rid, _ = om.run_greedy(seqs)
+        assert nxt.tolist() == rid.tolist()
+        # free a slot, reuse it with a long prompt alone (chunked prefill at 128 rows, then split-KV decode)
+        m.seq_free(1)
+        long_seq = [rng.integers(0, cfg.vocab_size, 700).tolist()]
+        for step in range(3):
+            ids, lg = m.step([7], long_seq, step == 0, want_logits=True)
+            rid, rlg = om.run_greedy(long_seq)
+            w = max(w, rel_err(lg[0], rlg[0]))
+            assert ids.tolist() == rid.tolist(), (bits, "long", step)
+            long_seq[0].append(int(rid[0]))
+        worst[bits] = w
+        assert w < LOGITS_TOL, (bits, w)
+        m.close()
+    print(f"[stress] small model, worst logits error: 24-bit V {worst[24]:.3e}, 16-bit V {worst[16]:.3e}")
+    assert worst[24] < worst[16] * 1.2
+    m64 = pkg.Qwen3ForCausalLM.from_synthetic(pkg.Qwen3Config.tiny(), 0, ctx)  # head_dim 64
+    m64.set_option("kv_v_bits", 24)
+    with pytest.raises(pkg._lib.NvllmError) as e:
+        m64.kv_alloc(4, 2, 64)
+    assert e.value.code == pkg._lib.EINVAL
+    with pytest.raises(pkg._lib.NvllmError):
+        m64.set_option("kv_v_bits", 20)
+    m64.close()
