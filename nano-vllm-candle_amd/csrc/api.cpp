@@ -2394,6 +2394,14 @@ extern "C" int nvllm_debug_xcc_map(nvllm_ctx* ctx, int gx, int gy, int gz, int t
 // `rot` weight copies are cycled so every launch streams cold HBM like the model does (1 = cache-warm).
 extern "C" int nvllm_debug_gemm_bench2(nvllm_ctx* ctx, int M, int N, int K, int mt, int nt, int nw, int n_split, int mode,
                                        int rot, int iters, float* us_per_call) {
+    // diagnostic build: mode 22 / 23 + 100 * a = ablation variant a of the streaming kernel (stream_gemm.hip ABL)
+    const int ablate = mode / 100;
+    mode %= 100;
+#ifdef NVLLM_STAMPS
+    nvllm::stream_gemm_set_ablate(ablate);
+#else
+    if (ablate) return fail(ctx, NVLLM_ESTATE, "ablation variants exist in the diagnostic build only (make stamps)");
+#endif
     if (!ctx || !us_per_call || M < 1 || (M > 128 && mode >= 10) || N % 32 || K % 128 || iters < 1 || rot < 1) return fail(ctx, NVLLM_EINVAL, "bad gemm_bench2 arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;

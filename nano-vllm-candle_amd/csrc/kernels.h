@@ -194,6 +194,7 @@ hipError_t launch_gemm_tile_qkv(const bf16_bits* xh, const bf16_bits* xl, const 
 #ifdef NVLLM_STAMPS
 void tile_gemm_stamps_arm(unsigned long long* base, int max_launches);  // diagnostic build
 int tile_gemm_stamps_count();
+void stream_gemm_set_ablate(int v);  // diagnostic build: ablation variant of the next streaming GEMM launches (stream_gemm.hip ABL)
 #endif
 hipError_t launch_xpack_plane(const bf16_bits* src, bf16_bits* dst, int M, int K, hipStream_t s);
 

@@ -28,11 +28,16 @@ namespace nvllm {
 // NTL: weight loads non-temporal.  Every weight byte is read once, by one workgroup, so it need not displace the x planes
 // and slabs other workgroups re-read; measured (interleaved A/B, batch 64): Qwen3-32B 19.1 -> 18.1 ms/step, Qwen3-8B
 // 6.37 -> 6.43 -- it pays on the big matrices, so the host sets it from the matrix size.
-template <int NT, int SC, int KC, int EPI, bool NTL>
-__global__ void __launch_bounds__(512) gemm_stream_kernel(StreamArgs a, const uint4* __restrict__ wp, int N, int KT, int kts) {
-    constexpr int MT = 4, NW = 8;
+// NW: waves per workgroup.  8 everywhere but for slab outputs (EPI 0), where the host may pick 10 or 13 so that the n-tiles
+// of a hidden size with a factor 5 (Qwen3-32B: 5120 = 320 tiles) or a very wide matrix (3200 tiles) still make ~256
+// workgroups: with 8 waves those shapes land on 200 of the 256 CUs.
+// ABL (diagnostic build only, tools/ablate_stream.py): 1 = no MFMAs and no LDS fragment reads, 2 = no x staging, 3 = no weight
+// loads, 4 = no slab stores -- what is left of the kernel's time says which part bounds it.  0 in every product launch.
+template <int NT, int SC, int KC, int EPI, bool NTL, int NW = 8, int ABL = 0>
+__global__ void __launch_bounds__(NW * 64) gemm_stream_kernel(StreamArgs a, const uint4* __restrict__ wp, int N, int KT, int kts) {
+    constexpr int MT = 4;
     constexpr int FRAGS = 2 * MT * KC;          // 1 KiB fragments per x chunk: [2 planes][MT][KC]
-    constexpr int PER_WAVE = FRAGS / NW;        // LDS-DMA loads per wave and chunk
+    constexpr int PER_WAVE = (FRAGS + NW - 1) / NW;  // LDS-DMA loads per wave and chunk (fragment f = wave + i * NW while f < FRAGS)
     static_assert(KC == 8 || KC == 4, "x chunks of 8 or 4 k-tiles");
     static_assert((KC == 8 && (SC == 4 || SC == 2)) || (KC == 4 && SC == 2), "the two weight sets alternate inside a chunk");
     static_assert(EPI != 2 || NT % 2 == 0, "SwiGLU pairs the gate and up tiles of a feature in one wave");
@@ -43,13 +48,12 @@ __global__ void __launch_bounds__(512) gemm_stream_kernel(StreamArgs a, const ui
     const int ntiles = N >> 4, M = a.M, ks = (int)gridDim.y;
     const int nt0 = ((int)blockIdx.x * NW + wave) * NT;
     const int kt_begin = (int)blockIdx.y * kts;
-    // this wave stages k-tile (wave % KC) of every chunk for PER_WAVE (plane, row block) pairs
-    const int kst = wave % KC;
+    // this wave stages fragments f = wave + i * NW of every chunk: f -> k-tile f % KC of (plane, row block) f / KC
     unsigned xoff[PER_WAVE];
     const unsigned xstep = a.x_packed ? 512u : 32u;
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
-        const int pb = (wave + i * NW) / KC, b = pb % MT;
+        const int f = min(wave + i * NW, FRAGS - 1), kst = f % KC, pb = f / KC, b = pb % MT;
         xoff[i] = a.x_packed ? (unsigned)((b * (a.ldx >> 5) + kt_begin + kst) * 512 + lane * 8)
                              : (unsigned)min(b * 16 + l15, M - 1) * (unsigned)a.ldx + (unsigned)((kt_begin + kst) * 32 + grp * 8);
     }
@@ -62,8 +66,10 @@ __global__ void __launch_bounds__(512) gemm_stream_kernel(StreamArgs a, const ui
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
             const int f = wave + i * NW, plane = (f / KC) / MT;
-            const uint16_t* src = (plane ? a.xl : a.xh) + (size_t)(xoff[i] + (unsigned)(c * KC) * xstep);
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (size_t)(buf * FRAGS + f) * 64), 16, 0, 0);
+            if (ABL != 2 && (FRAGS % NW == 0 || f < FRAGS)) {  // wave-uniform
+                const uint16_t* src = (plane ? a.xl : a.xh) + (size_t)(xoff[i] + (unsigned)(c * KC) * xstep);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (size_t)(buf * FRAGS + f) * 64), 16, 0, 0);
+            }
         }
     };
     uint4 wA[NT][SC], wB[NT][SC];
@@ -75,11 +81,19 @@ __global__ void __launch_bounds__(512) gemm_stream_kernel(StreamArgs a, const ui
 #pragma unroll
             for (int j = 0; j < SC; ++j) {
                 const uint4* pw = wp + ((size_t)ntc * KT + kt + j) * 64 + lane;
-                w[t][j] = NTL ? ld_stream16(pw) : *pw;
+                if constexpr (ABL == 3) w[t][j] = make_uint4(0, 0, 0, 0);
+                else w[t][j] = NTL ? ld_stream16(pw) : *pw;
             }
         }
     };
     auto compute = [&](int k0, int buf, const uint4 (&w)[NT][SC]) {
+        if constexpr (ABL == 1) {  // the weight registers stay live (their loads are waited for), nothing is computed
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < SC; ++j) asm volatile("" ::"v"(w[t][j].x), "v"(w[t][j].y), "v"(w[t][j].z), "v"(w[t][j].w));
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < SC; ++j)
 #pragma unroll
@@ -130,7 +144,7 @@ __global__ void __launch_bounds__(512) gemm_stream_kernel(StreamArgs a, const ui
     }
     // ---- slabs / in-launch combine ------------------------------------------------------------------------------
     const size_t slab_stride = (size_t)M * N;
-    if (EPI == 0 || ks > 1) {
+    if (ABL != 4 && (EPI == 0 || ks > 1)) {
         float* o = a.slabs + (size_t)blockIdx.y * slab_stride;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -287,66 +301,95 @@ __global__ void __launch_bounds__(512) gemm_stream_kernel(StreamArgs a, const ui
 }
 
 // (n-tiles per wave, K slices, x chunk depth): about one 8-wave workgroup per CU, at most one round of the chip
-struct StreamShape { int nt, ks, kc; };
+struct StreamShape { int nt, ks, kc, nw; };
 static StreamShape stream_shape(int M, int N, int K, int epi, bool any_size) {
-    StreamShape none{0, 0, 0};
+    StreamShape none{0, 0, 0, 8};
     if (M <= 16 || M > 64 || N % 16 || K % 32) return none;
     if (!any_size && (size_t)N * K * 2 < ((size_t)24 << 20)) return none;  // small matrices: whole-K kernels when they apply
     if (epi == 2 && (N / 16) % 2) return none;
     const int KT = K / 32, ntiles = N / 16;
     StreamShape best = none;
     int best_wgs = 0;
-    for (int kc : {8, 4})
-        for (int nt = 4; nt >= 1; --nt) {
-            if (epi == 2 && nt % 2) continue;
-            if (epi != 2 && nt == 4) continue;  // 4 tiles per wave only where SwiGLU needs pairs and 2 leave too many workgroups
-            for (int ks = 1; ks <= 16; ++ks) {
-                if (KT % ks || (KT / ks) % kc || KT / ks < 2 * kc) continue;
-                const int ngroups = ((ntiles + nt - 1) / nt + 7) / 8;
-                if (epi == 3 && ngroups > 64) continue;  // deferred-norm consumers sum <= 64 ssq groups
-                const int wgs = ngroups * ks;
-                // most workgroups within one round of the chip; ties: deep x chunks, then fewer slices (fewer slabs)
-                if (wgs <= 256 && (wgs > best_wgs || (wgs == best_wgs && kc == best.kc && ks < best.ks))) { best_wgs = wgs; best = StreamShape{nt, ks, kc}; }
+    for (int nw : {8, 10, 13}) {  // 8 first: a wider workgroup must bring strictly more workgroups to be taken
+        if (nw != 8 && (epi != 0 || M <= 16)) continue;  // only the slab form is instantiated for 10 / 13 waves
+        for (int kc : {8, 4})
+            for (int nt = 4; nt >= 1; --nt) {
+                if (epi == 2 && nt % 2) continue;
+                if (epi != 2 && nt == 4) continue;  // 4 tiles per wave only where SwiGLU needs pairs and 2 leave too many workgroups
+                if (nw == 13 && nt > 2) continue;   // 13 waves: 4 on one SIMD, <= 128 registers
+                for (int ks = 1; ks <= 16; ++ks) {
+                    if (KT % ks || (KT / ks) % kc || KT / ks < 2 * kc) continue;
+                    const int ngroups = ((ntiles + nt - 1) / nt + nw - 1) / nw;
+                    if (epi == 3 && ngroups > 64) continue;  // deferred-norm consumers sum <= 64 ssq groups
+                    const int wgs = ngroups * ks;
+                    // most workgroups within one round of the chip; ties: deep x chunks, then fewer slices (fewer slabs)
+                    if (wgs <= 256 && (wgs > best_wgs || (wgs == best_wgs && nw == best.nw && kc == best.kc && ks < best.ks))) { best_wgs = wgs; best = StreamShape{nt, ks, kc, nw}; }
+                }
             }
-        }
+    }
     return best_wgs >= (any_size ? 48 : 128) ? best : none;
 }
 int gemm_stream_splits(int M, int N, int K) { return stream_shape(M, N, K, 0, false).ks; }
 bool gemm_stream_ok(int M, int N, int K, int epi) { return stream_shape(M, N, K, epi, true).nt != 0; }
 int gemm_stream_groups(int M, int N, int K, int epi) {
     const StreamShape sh = stream_shape(M, N, K, epi, true);
-    return sh.nt ? ((N / 16 + sh.nt - 1) / sh.nt + 7) / 8 : 0;
+    return sh.nt ? ((N / 16 + sh.nt - 1) / sh.nt + sh.nw - 1) / sh.nw : 0;
 }
 size_t gemm_stream_slab_floats(int M, int N, int K, int epi) {
     const StreamShape sh = stream_shape(M, N, K, epi, true);
     return sh.nt ? (size_t)sh.ks * M * N : 0;
 }
 
-template <int NT, int SC, int KC, int EPI>
+#ifdef NVLLM_STAMPS
+static int g_stream_ablate = 0;
+void stream_gemm_set_ablate(int v) { g_stream_ablate = v; }
+#endif
+template <int NT, int SC, int KC, int EPI, int NW>
 static hipError_t stream_launch_t(const StreamShape& sh, const StreamArgs& a, const PackedW& w, hipStream_t s) {
     const size_t lds = (size_t)2 * (2 * 4 * KC) * 1024;
     const int waves = (w.N / 16 + NT - 1) / NT;
-    dim3 grid((waves + 7) / 8, sh.ks);
+    dim3 grid((waves + NW - 1) / NW, sh.ks);
+#ifdef NVLLM_STAMPS
+    if constexpr (EPI == 0 && NT == 1) {
+        if (g_stream_ablate) {
+            static std::atomic<uint64_t> lds_set_ab{0};
+#define NVLLM_AB(V_)                                                                                                             \
+    if (g_stream_ablate == V_) {                                                                                                 \
+        ensure_dyn_lds(reinterpret_cast<const void*>(gemm_stream_kernel<NT, SC, KC, EPI, true, NW, V_>), lds, lds_set_ab);       \
+        gemm_stream_kernel<NT, SC, KC, EPI, true, NW, V_><<<grid, NW * 64, lds, s>>>(a, w.data, w.N, w.K / 32, w.K / 32 / sh.ks); \
+        return hipGetLastError();                                                                                                \
+    }
+            NVLLM_AB(1) NVLLM_AB(2) NVLLM_AB(3) NVLLM_AB(4)
+#undef NVLLM_AB
+        }
+    }
+#endif
     constexpr size_t nt_min_bytes = (size_t)80 << 20;  // measured: 32B shards gain from 80 MB up, 8B matrices below lose
     if (w.bytes() >= nt_min_bytes) {  // big matrix: non-temporal weight stream
         static std::atomic<uint64_t> lds_set_nt{0};
-        ensure_dyn_lds(reinterpret_cast<const void*>(gemm_stream_kernel<NT, SC, KC, EPI, true>), lds, lds_set_nt);
-        gemm_stream_kernel<NT, SC, KC, EPI, true><<<grid, 512, lds, s>>>(a, w.data, w.N, w.K / 32, w.K / 32 / sh.ks);
+        ensure_dyn_lds(reinterpret_cast<const void*>(gemm_stream_kernel<NT, SC, KC, EPI, true, NW>), lds, lds_set_nt);
+        gemm_stream_kernel<NT, SC, KC, EPI, true, NW><<<grid, NW * 64, lds, s>>>(a, w.data, w.N, w.K / 32, w.K / 32 / sh.ks);
         return hipGetLastError();
     }
     static std::atomic<uint64_t> lds_set{0};
-    ensure_dyn_lds(reinterpret_cast<const void*>(gemm_stream_kernel<NT, SC, KC, EPI, false>), lds, lds_set);
-    gemm_stream_kernel<NT, SC, KC, EPI, false><<<grid, 512, lds, s>>>(a, w.data, w.N, w.K / 32, w.K / 32 / sh.ks);
+    ensure_dyn_lds(reinterpret_cast<const void*>(gemm_stream_kernel<NT, SC, KC, EPI, false, NW>), lds, lds_set);
+    gemm_stream_kernel<NT, SC, KC, EPI, false, NW><<<grid, NW * 64, lds, s>>>(a, w.data, w.N, w.K / 32, w.K / 32 / sh.ks);
     return hipGetLastError();
 }
 template <int EPI>
 static hipError_t stream_dispatch(const StreamShape& sh, const StreamArgs& a, const PackedW& w, hipStream_t s) {
     // set depth made no difference on MI355X (2- vs 4-k-tile sets, tools/probe_lm.py): the shallow ones use fewer registers
-#define NVLLM_ST(NT_, SC_, KC_) if (sh.nt == NT_ && sh.kc == KC_) return stream_launch_t<NT_, SC_, KC_, EPI>(sh, a, w, s);
+#define NVLLM_ST(NT_, SC_, KC_) if (sh.nt == NT_ && sh.kc == KC_ && sh.nw == 8) return stream_launch_t<NT_, SC_, KC_, EPI, 8>(sh, a, w, s);
+#define NVLLM_STW(NT_, SC_, KC_, NW_) if (sh.nt == NT_ && sh.kc == KC_ && sh.nw == NW_) return stream_launch_t<NT_, SC_, KC_, EPI, NW_>(sh, a, w, s);
     if constexpr (EPI != 2) { NVLLM_ST(1, 4, 8) NVLLM_ST(1, 2, 4) NVLLM_ST(3, 2, 8) NVLLM_ST(3, 2, 4) }
     NVLLM_ST(2, 2, 8) NVLLM_ST(2, 2, 4)
     if constexpr (EPI == 2) { NVLLM_ST(4, 2, 8) NVLLM_ST(4, 2, 4) }
+    if constexpr (EPI == 0) {
+        NVLLM_STW(1, 4, 8, 10) NVLLM_STW(1, 2, 4, 10) NVLLM_STW(2, 2, 8, 10) NVLLM_STW(2, 2, 4, 10) NVLLM_STW(3, 2, 8, 10) NVLLM_STW(3, 2, 4, 10)
+        NVLLM_STW(1, 4, 8, 13) NVLLM_STW(1, 2, 4, 13) NVLLM_STW(2, 2, 8, 13) NVLLM_STW(2, 2, 4, 13)
+    }
 #undef NVLLM_ST
+#undef NVLLM_STW
     return hipErrorNotSupported;
 }
 hipError_t launch_gemm_stream_epi(const StreamArgs& a, const PackedW& w, int epi, hipStream_t s) {
