@@ -28,8 +28,16 @@ int nvllm_ctx_create_null_comm(int device_ordinal, int tp_rank, int tp_size, nvl
  * elapsed ms and the number of launches since the last read. */
 int nvllm_profile_kernel(nvllm_model* m, int kind);
 int nvllm_profile_read(nvllm_model* m, double* total_ms, int64_t* launches);
-/* tuning switches of a model (A/B runs and tests).  "stream_combine" (default 0): let the fused forward use the streaming
- * GEMM's in-launch split-K combine epilogues (fewer launches; measured slower on MI355X than slabs + a consumer launch). */
+/* Per-model options (A/B runs, tests, and two deployment knobs).  The library reads no environment variable.
+ *   "kv_v_bits" (16 | 24; takes effect at the next nvllm_kv_alloc): 24 keeps V as f16 + a bf8 residual byte (13..14 bits;
+ *       V bytes x1.5; head_dim 128 only) -- the knob for holding the 1e-3 logits bar on heavy-tailed checkpoints;
+ *   "oneshot_allreduce" (0 | 1; at the next nvllm_kv_alloc, every rank alike): one-shot all-reduce for decode messages;
+ *       "oneshot_spins": bound of its wait kernel's poll; "oneshot_skip_push": test hook (this rank skips N pushes);
+ *   "stream_combine" (default 0): let the fused forward use the streaming GEMM's in-launch split-K combine epilogues (fewer
+ *       launches; measured slower on MI355X than slabs + a consumer launch);
+ *   "tile_min_wgs" (default 192; 0 never, 1 whenever the shape fits), "tile_fuse_qk" (default 1): the prefill tile GEMM;
+ *   "no_fused", "no_xpack", "no_rowpar", "no_attn_prologue" (default 0): force the generic decode path / row-major planes /
+ *       no whole-K row-parallel GEMMs / q,k-norm + RoPE + KV write in their own row kernel. */
 int nvllm_debug_set_option(nvllm_model* m, const char* name, int value);
 
 /* counters for tests: "oneshot_calls" = all-reduces run on the one-shot device path by this model's context;
