@@ -71,6 +71,15 @@ for layer in (10, 11, 12):
                 x = st[ws][:, :4]
                 life[r] = (x[:, :, 4].max() - x[:, :, 0][x[:, :, 0] > 0].min()) / 100.0
             q = [0, 8, 16, 32, 48, 63]
+            if layer == 11:
+                # per rank: when (relative to the kernel's first entry) each stamp is reached, median over heads and waves
+                for r in q:
+                    x = st[[r + 64 * h for h in range(8)]][:, :4, :5].astype(np.float64)
+                    x[x == 0] = np.nan
+                    rel = (x - k0) / 100.0
+                    print(f"      rank #{r} ctx {ctx_lens[order[r]]}: stamps 0..4 at (median over heads/waves) "
+                          + "  ".join(f"{np.nanmedian(rel[:, :, i]):.1f}" for i in range(5))
+                          + "  | per wave end of loop (stamp 3), head 0: " + " ".join(f"{v:.1f}" for v in rel[0, :, 3]))
             print("      attention lifetime by rank (ctx): " + "  ".join(f"#{r} ({ctx_lens[order[r]]}) {life[r]:.1f}" for r in q),
                   f"| end of last WG by rank: " + "  ".join(f"#{r} {(st[[r + 64 * h for h in range(8)]][:, :4, 4].max() - k0) / 100.0:.1f}" for r in q))
         prev_end = k4
