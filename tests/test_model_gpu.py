@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from tests.test_golden import load_golden, split_prompts
-from tests.util import LOGITS_TOL, oracle_config, rel_err, row_rel_err
+from tests.util import LOGITS_TOL, oracle_config, random_calls, rel_err, row_rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -455,100 +455,6 @@ def test_random_call_sequences_match_the_oracle(pkg, ctx, oracle, seed, kw, v_bi
         m.set_option("kv_v_bits", v_bits)
     m.kv_alloc(NB, MS, 96)
     om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(seed)
-    rng = np.random.default_rng(seed)
-    live = {}           # seq_id -> tokens the GPU has been shown plus the one it has just produced
-    next_new = 0
-    lens_menu = [1, 2, 15, 16, 17, 31, 33, 64, 100, 255, 256, 257, 300]
-    worst = 0.0
-
-    def blocks_of(n):
-        return (n + 255) // 256
-
-    def check(ids, got_ids, got_lg):
-        nonlocal worst
-        for k, sid in enumerate(ids):
-            rid, rlg = om.run_greedy([live[sid]])
-            if got_lg is not None:
-                e = row_rel_err(got_lg[k:k + 1], rlg)
-                worst = max(worst, e)
-                assert e < LOGITS_TOL, (sid, len(live[sid]), e)
-            assert int(got_ids[k]) == int(rid[0]), (sid, len(live[sid]))
-            live[sid].append(int(rid[0]))
-
-    def pool_ok():
-        # the token just produced is not in the cache yet: a sequence of n shown tokens holds blocks for n
-        assert m.free_blocks() == NB - sum(blocks_of(len(t) - 1) for t in live.values())
-
-    ops = 0
-    for it in range(110):
-        op = rng.choice(["add", "decode", "resident", "pipelined", "grow", "reprefill", "free"], p=[0.22, 0.28, 0.12, 0.08, 0.1, 0.08, 0.12])
-        if op == "add" or not live:
-            n_new = int(rng.integers(1, 3))
-            ids, ps = [], []
-            for _ in range(n_new):
-                if len(live) + len(ids) >= MS:
-                    break
-                n = int(rng.choice(lens_menu))
-                used = sum(blocks_of(len(t) + 4) for t in live.values()) + sum(blocks_of(len(p) + 4) for p in ps)
-                if used + blocks_of(n + 4) > NB:
-                    continue
-                # an id freed earlier may come back (llm_engine.rs never reuses ids, the ABI allows it)
-                sid = next_new if rng.random() < 0.7 else int(rng.integers(0, next_new + 1))
-                if sid in live or sid in ids:
-                    sid = next_new
-                next_new = max(next_new, sid + 1)
-                ids.append(sid)
-                ps.append(rng.integers(3, cfg.vocab_size, n).tolist())
-            if not ids:
-                continue
-            for sid, p in zip(ids, ps):
-                live[sid] = list(p)
-            got, lg = m.step(ids, [live[s] for s in ids], True, want_logits=True)
-            check(ids, got, lg)
-        elif op == "decode":
-            ids = [int(s) for s in rng.permutation(list(live))[: int(rng.integers(1, len(live) + 1))]]
-            if any(blocks_of(len(live[s])) > blocks_of(len(live[s]) - 1) for s in ids) and m.free_blocks() < len(ids):
-                continue
-            got, lg = m.step(ids, [live[s] for s in ids], False, want_logits=True)
-            check(ids, got, lg)
-        elif op in ("resident", "pipelined"):
-            ids = [int(s) for s in rng.permutation(list(live))[: int(rng.integers(1, len(live) + 1))]]
-            k = int(rng.integers(1, 4))
-            if m.free_blocks() < len(ids) * 1:
-                continue
-            got, lg = m.step(ids, [live[s] for s in ids], False, want_logits=True)
-            check(ids, got, lg)
-            if op == "resident":
-                for _ in range(k):
-                    check(ids, m.decode_next(), None)
-            else:
-                for _ in range(k):
-                    m.decode_enqueue()
-                for _ in range(k):
-                    check(ids, m.decode_collect(), None)
-        elif op == "grow":
-            # the caller shows a sequence again with several more tokens than the cache holds (its own tokens: any ids do)
-            sid = int(rng.choice(list(live)))
-            extra = int(rng.integers(2, 40))
-            if blocks_of(len(live[sid]) + extra) - blocks_of(len(live[sid]) - 1) > m.free_blocks():
-                continue
-            live[sid] += rng.integers(3, cfg.vocab_size, extra).tolist()
-            got, lg = m.step([sid], [live[sid]], False, want_logits=True)
-            check([sid], got, lg)
-        elif op == "reprefill":
-            sid = int(rng.choice(list(live)))
-            if m.free_blocks() < 1:
-                continue
-            got, lg = m.step([sid], [live[sid]], True, want_logits=True)
-            check([sid], got, lg)
-        else:
-            sid = int(rng.choice(list(live)))
-            m.seq_free(sid)
-            del live[sid]
-        pool_ok()
-        ops += 1
+    ops, worst = random_calls(m, om, cfg, seed, 110, NB, MS)
     assert ops >= 60
-    for sid in list(live):
-        m.seq_free(sid)
-    assert m.free_blocks() == NB
     print(f"random call sequences (seed {seed}, {kw}, V {v_bits} bits): {ops} calls, worst logits error {worst:.2e}")

@@ -7,7 +7,7 @@ import threading
 import numpy as np
 import pytest
 
-from tests.util import LOGITS_TOL, oracle_config, row_rel_err
+from tests.util import LOGITS_TOL, oracle_config, random_calls, row_rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -72,6 +72,39 @@ def test_tp_equals_tp1(tp, kw, oracle):
     rid, _ = om.run_greedy(ref_seqs)
     for rank in range(tp):
         assert res[rank][1].tolist() == rid.tolist()
+
+
+def test_tp_random_call_sequences_match_the_oracle(oracle):
+    # the seeded random caller of tests/test_model_gpu.py on a TP = 2 group: every rank makes the same calls (the reference's
+    # one-process-per-rank model, tp.rs:21-31) and checks ids and gathered logits against the oracle by itself
+    import nano_vllm_candle_amd as pkg
+
+    cfg = pkg.Qwen3Config.tiny()
+    tp, NB, MS, seed = 2, 20, 6, 21
+    lock = threading.Lock()
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(seed)
+    results, errors = [None] * tp, []
+
+    def worker(rank):
+        try:
+            ctx = pkg.Context(0, tp_rank=rank, tp_size=tp, loopback_group="grandom")
+            m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=seed, ctx=ctx)
+            m.kv_alloc(NB, MS, 96)
+            results[rank] = random_calls(m, om, cfg, seed, 60, NB, MS, lock=lock)
+            m.close()
+            ctx.close()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(tp)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not errors, errors
+    assert all(r is not None for r in results), "a rank hung"
+    assert results[0] == results[1] and results[0][0] >= 30, results
+    print(f"TP = 2 random call sequences: {results[0][0]} calls, worst logits error {results[0][1]:.2e}")
 
 
 @pytest.mark.parametrize("fuse_qk", [1, 0])
