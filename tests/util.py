@@ -27,7 +27,7 @@ def bf16_round(a):
 LOGITS_TOL = 1e-3  # BASELINE.json north_star: logits within 1e-3 relative of the reference CPU path
 
 
-def random_calls(m, om, cfg, seed, iters, NB, MS, lock=None):
+def random_calls(m, om, cfg, seed, iters, NB, MS, lock=None, max_new=2, lens_menu=None):
     """Drive model m (pool of NB blocks, MS sequence slots) with a seeded random caller and check every call against the
     oracle model om (its dense re-forward of each sequence on its own); returns (calls made, worst logits error).
     lock: serialises the oracle calls when several rank threads drive the same sequence (tensor-parallel test)."""
@@ -39,8 +39,9 @@ def random_calls(m, om, cfg, seed, iters, NB, MS, lock=None):
     rng = np.random.default_rng(seed)
     live = {}           # seq_id -> tokens the GPU has been shown plus the one it has just produced
     next_new = 0
-    lens_menu = [1, 2, 15, 16, 17, 31, 33, 64, 100, 255, 256, 257, 300]
+    lens_menu = lens_menu or [1, 2, 15, 16, 17, 31, 33, 64, 100, 255, 256, 257, 300]
     worst = 0.0
+    ties = []  # accepted near-ties (relative gap of the two logits in the oracle)
 
     def blocks_of(n):
         return (n + 255) // 256
@@ -54,8 +55,14 @@ def random_calls(m, om, cfg, seed, iters, NB, MS, lock=None):
                 e = row_rel_err(got_lg[k:k + 1], rlg)
                 worst = max(worst, e)
                 assert e < LOGITS_TOL, (sid, len(live[sid]), e)
-            assert int(got_ids[k]) == int(rid[0]), (sid, len(live[sid]))
-            live[sid].append(int(rid[0]))
+            gid = int(got_ids[k])
+            if gid != int(rid[0]):
+                # two logits closer than twice the tolerance may swap places: a tie, not an error ("ids exact where the
+                # margin is clear"); the caller goes on with the GPU's choice, as the device-fed decode already has
+                gap = float(rlg[0, int(rid[0])] - rlg[0, gid]) / float(np.abs(rlg).max())
+                assert 0.0 <= gap <= 2 * LOGITS_TOL, (sid, len(live[sid]), gid, int(rid[0]), gap)
+                ties.append(gap)
+            live[sid].append(gid)
 
     def pool_ok():
         # the token just produced is not in the cache yet: a sequence of n shown tokens holds blocks for n
@@ -65,7 +72,7 @@ def random_calls(m, om, cfg, seed, iters, NB, MS, lock=None):
     for it in range(iters):
         op = rng.choice(["add", "decode", "resident", "pipelined", "grow", "reprefill", "free"], p=[0.22, 0.28, 0.12, 0.08, 0.1, 0.08, 0.12])
         if op == "add" or not live:
-            n_new = int(rng.integers(1, 3))
+            n_new = int(rng.integers(1, max_new + 1))
             ids, ps = [], []
             for _ in range(n_new):
                 if len(live) + len(ids) >= MS:
@@ -132,4 +139,5 @@ def random_calls(m, om, cfg, seed, iters, NB, MS, lock=None):
     for sid in list(live):
         m.seq_free(sid)
     assert m.free_blocks() == NB
+    assert len(ties) <= max(3, ops // 20), ties  # ties are rare by construction
     return ops, worst
