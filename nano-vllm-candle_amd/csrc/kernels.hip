@@ -1608,8 +1608,12 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1
     const int kh = blockIdx.y;
     NVLLM_STAMP(a, 0);
     if (a.tile_order) {
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-        const int rank = ((lin >> 8) & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+        // The direction is a property of the whole grid row (one kv head): decided per workgroup from its own linear id,
+        // a row that straddles a multiple of 256 walked partly forwards and partly backwards -- some tiles twice, others
+        // never (found by tools/fuzz_calls.py: any batch that does not divide 256 once batch x kv heads exceeds 256,
+        // e.g. 40 sequences on 8 kv heads).
+        const int lin0 = blockIdx.y * gridDim.x;
+        const int rank = ((lin0 >> 8) & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
         tile = a.tile_order[rank];
     }
     // fused decode: every q-tile is one row and tile i is row i (no tile_row0/tile_nrows round trip)

@@ -458,3 +458,29 @@ def test_random_call_sequences_match_the_oracle(pkg, ctx, oracle, seed, kw, v_bi
     ops, worst = random_calls(m, om, cfg, seed, 110, NB, MS)
     assert ops >= 60
     print(f"random call sequences (seed {seed}, {kw}, V {v_bits} bits): {ops} calls, worst logits error {worst:.2e}")
+
+
+@pytest.mark.parametrize("kw,B", [(dict(num_attention_heads=32, num_key_value_heads=32), 12),   # 384 workgroups, rows of 12
+                                  (dict(hidden_size=1024, head_dim=128, num_attention_heads=16, num_key_value_heads=8,
+                                        intermediate_size=3072, vocab_size=2048), 40),           # 0.6B layer shapes, 320 workgroups
+                                  (dict(num_attention_heads=8, num_key_value_heads=8), 100)])    # 800 workgroups, rows of 100
+def test_decode_batches_that_do_not_divide_256(pkg, ctx, oracle, kw, B):
+    # Regression (found by tools/fuzz_calls.py): the decode attention grid is (sequences, kv heads) and walks the
+    # longest-first order backwards in odd 256-workgroup rounds; with the direction taken per workgroup, a grid row that
+    # straddled a multiple of 256 computed some (sequence, head) pairs twice and others never.  Every batch size that divides
+    # 256 (all the earlier tests) was blind to it.
+    cfg = pkg.Qwen3Config.tiny(**kw)
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 6, ctx)
+    m.kv_alloc(B + 2, B, 256)
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(6)
+    rng = np.random.default_rng(5)
+    seqs = [rng.integers(3, cfg.vocab_size, int(n)).tolist() for n in rng.integers(1, 70, B)]
+    ids = list(range(B))
+    for step in range(3):
+        got, lg = m.step(ids, seqs, step == 0, want_logits=True)
+        rid, rlg = om.run_greedy(seqs)
+        errs = [row_rel_err(lg[i:i + 1], rlg[i:i + 1]) for i in range(B)]
+        assert max(errs) < LOGITS_TOL, (step, [i for i, e in enumerate(errs) if e >= LOGITS_TOL][:8], max(errs))
+        for s, t in zip(seqs, got):
+            s.append(int(t))
+    m.close()

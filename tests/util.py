@@ -42,6 +42,7 @@ def random_calls(m, om, cfg, seed, iters, NB, MS, lock=None, max_new=2, lens_men
     lens_menu = lens_menu or [1, 2, 15, 16, 17, 31, 33, 64, 100, 255, 256, 257, 300]
     worst = 0.0
     ties = []  # accepted near-ties (relative gap of the two logits in the oracle)
+    cur_op = [""]  # for the assertion messages
 
     def blocks_of(n):
         return (n + 255) // 256
@@ -54,13 +55,13 @@ def random_calls(m, om, cfg, seed, iters, NB, MS, lock=None, max_new=2, lens_men
             if got_lg is not None:
                 e = row_rel_err(got_lg[k:k + 1], rlg)
                 worst = max(worst, e)
-                assert e < LOGITS_TOL, (sid, len(live[sid]), e)
+                assert e < LOGITS_TOL, (cur_op[0], len(ids), sid, len(live[sid]), e)
             gid = int(got_ids[k])
             if gid != int(rid[0]):
                 # two logits closer than twice the tolerance may swap places: a tie, not an error ("ids exact where the
                 # margin is clear"); the caller goes on with the GPU's choice, as the device-fed decode already has
                 gap = float(rlg[0, int(rid[0])] - rlg[0, gid]) / float(np.abs(rlg).max())
-                assert 0.0 <= gap <= 2 * LOGITS_TOL, (sid, len(live[sid]), gid, int(rid[0]), gap)
+                assert 0.0 <= gap <= 2 * LOGITS_TOL, (cur_op[0], len(ids), sid, len(live[sid]), gid, int(rid[0]), gap)
                 ties.append(gap)
             live[sid].append(gid)
 
@@ -71,6 +72,7 @@ def random_calls(m, om, cfg, seed, iters, NB, MS, lock=None, max_new=2, lens_men
     ops = 0
     for it in range(iters):
         op = rng.choice(["add", "decode", "resident", "pipelined", "grow", "reprefill", "free"], p=[0.22, 0.28, 0.12, 0.08, 0.1, 0.08, 0.12])
+        cur_op[0] = f"call {it} {op}"
         if op == "add" or not live:
             n_new = int(rng.integers(1, max_new + 1))
             ids, ps = [], []
