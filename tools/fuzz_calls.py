@@ -14,6 +14,18 @@ from tests.util import oracle_config, random_calls  # noqa: E402
 
 import numpy as np  # noqa: E402
 
+import threading  # noqa: E402
+
+tp = 1
+if "--tp" in sys.argv:
+    i = sys.argv.index("--tp")
+    tp = int(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
+only = None
+if "--only" in sys.argv:
+    i = sys.argv.index("--only")
+    only = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
 random_n = 0
 if len(sys.argv) > 1 and sys.argv[1] == "--random-configs":
     random_n = int(sys.argv[2])
@@ -21,7 +33,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--random-configs":
     n_seeds = 1
 else:
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-ctx = pkg.Context(0)
+ctx = pkg.Context(0) if tp == 1 else None
 T = pkg.Qwen3Config.tiny
 short = [1, 2, 3, 7, 15, 16, 17, 31, 32, 33, 48, 64, 65]
 cases = [
@@ -35,6 +47,13 @@ cases = [
                                           intermediate_size=3072, vocab_size=2048), 64, 28, 128, 6, short + [100, 255, 256, 257], {"kv_v_bits": 24}),
     ("0.6B layer shapes x 2, tile GEMM on every prompt chunk", T(hidden_size=1024, head_dim=128, num_attention_heads=16, num_key_value_heads=8,
                                                                 intermediate_size=3072, vocab_size=2048), 48, 12, 512, 3, [100, 255, 256, 257, 300, 390], {"tile_min_wgs": 1}),
+    ("tiny kv 8, up to 130 short sequences (fused path to 128 rows, generic beyond)", T(num_attention_heads=8, num_key_value_heads=8), 140, 130, 96, 40,
+     [1, 2, 3, 5, 9, 17, 30], {}),
+    ("0.6B layer shapes x 1, up to 100 short sequences", T(hidden_size=1024, head_dim=128, num_attention_heads=16, num_key_value_heads=8,
+                                                          intermediate_size=3072, vocab_size=2048, num_hidden_layers=1), 110, 100, 256, 30, [1, 2, 3, 5, 9, 17, 30], {}),
+    ("8B layer shapes x 1 (streaming GEMMs at 17..64 rows, other kernels around them)", T(hidden_size=4096, head_dim=128, num_attention_heads=32,
+                                                                                        num_key_value_heads=8, intermediate_size=12288, vocab_size=1024, num_hidden_layers=1),
+     80, 72, 256, 24, [1, 2, 3, 5, 8], {}),
     ("0.6B layer shapes x 2, no fused path", T(hidden_size=1024, head_dim=128, num_attention_heads=16, num_key_value_heads=8,
                                               intermediate_size=3072, vocab_size=2048), 64, 28, 128, 6, short + [255, 257], {"no_fused": 1}),
 ]
@@ -44,7 +63,7 @@ if random_n:
     named = [dict(hidden_size=2048, head_dim=128, num_attention_heads=16, num_key_value_heads=8, intermediate_size=6144),   # 1.7B layer
              dict(hidden_size=2560, head_dim=128, num_attention_heads=32, num_key_value_heads=8, intermediate_size=9728)]   # 4B layer
     for i in range(random_n):
-        if i < len(named):
+        if i < len(named) and tp == 1:
             kw = dict(named[i], num_hidden_layers=1, vocab_size=1024)
         else:
             hd = int(rng.choice([64, 128]))
@@ -64,21 +83,70 @@ if random_n:
             opts["tile_min_wgs"] = 1
         cases.append((f"random {kw} {opts}", T(**kw), 64, int(rng.choice([6, 20, 28])), int(rng.choice([16, 48, 128, 512])),
                       int(rng.integers(2, 7)), menu, opts))
+
+
+class CachedOracle:
+    """the rank threads of a TP group make the same calls: one oracle forward serves them all (called under the lock)"""
+
+    def __init__(self, om):
+        self.om, self.memo = om, {}
+
+    def run_greedy(self, seqs):
+        key = tuple(tuple(x) for x in seqs)
+        if key not in self.memo:
+            if len(self.memo) > 8:
+                self.memo.clear()
+            self.memo[key] = self.om.run_greedy(seqs)
+        return self.memo[key]
+
+
 bad = 0
+group = 0
 for name, cfg, NB, MS, mbt, max_new, menu, opts in cases:
+    if only and only not in name:
+        continue
+    if tp > 1 and (cfg.num_key_value_heads % tp or cfg.intermediate_size % (128 * tp) or cfg.vocab_size % (16 * tp)
+                   or (cfg.num_attention_heads // tp * cfg.head_dim) % 128):
+        continue
     for seed in (range(first_seed, first_seed + 1) if random_n else range(100, 100 + n_seeds)):
         t0 = time.time()
-        m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed, ctx)
-        for k, v in opts.items():
-            m.set_option(k, v)
-        m.kv_alloc(NB, MS, mbt)
-        om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(seed)
-        try:
-            ops, worst = random_calls(m, om, cfg, seed, 60 if random_n else 120, NB, MS, max_new=max_new, lens_menu=menu)
-            print(f"ok   {name}: seed {seed}, {ops} calls, worst {worst:.2e}, {time.time() - t0:.1f} s", flush=True)
-        except Exception as e:  # noqa: BLE001
+        iters = 24 if "8B" in name else (60 if random_n else 120)
+        om = CachedOracle(oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(seed))
+        res, errs = [None] * tp, []
+        lock = threading.Lock()
+        group += 1
+
+        def worker(rank):
+            try:
+                c = ctx if tp == 1 else pkg.Context(0, tp_rank=rank, tp_size=tp, loopback_group=f"fz{group}")
+                m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed, c)
+                for k, v in opts.items():
+                    m.set_option(k, v)
+                m.kv_alloc(NB, MS, mbt)
+                res[rank] = random_calls(m, om, cfg, seed, iters, NB, MS, max_new=max_new, lens_menu=menu, lock=lock if tp > 1 else None)
+                m.close()
+                if tp > 1:
+                    c.close()
+            except BaseException as e:  # noqa: BLE001
+                errs.append(f"rank {rank}: {type(e).__name__}: {str(e)[:300]}")
+
+        if tp == 1:
+            worker(0)
+        else:
+            th = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(tp)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join(timeout=600)
+            if any(r is None for r in res) and not errs:
+                errs.append("a rank hung")
+        if errs:
             bad += 1
-            print(f"FAIL {name}: seed {seed}: {type(e).__name__}: {str(e)[:300]}", flush=True)
-        m.close()
+            print(f"FAIL {name}: seed {seed}: {errs[0]}", flush=True)
+            if tp > 1:
+                print("failures so far:", bad, "(a failed TP group may leave rank threads behind: stopping)")
+                os._exit(1)
+        else:
+            print(f"ok   {name}: seed {seed}, {res[0][0]} calls, worst {res[0][1]:.2e}, {time.time() - t0:.1f} s", flush=True)
 print("failures:", bad)
 sys.exit(1 if bad else 0)
