@@ -429,3 +429,34 @@ def test_8b_full_size_batch256_context4096_properties(pkg, ctx):
         assert e < 5e-4
         m.seq_free(1000 + j)
     m.close()
+
+
+def test_full_vocabulary_lm_head_and_decode_kernels_at_odd_batch_sizes(pkg, ctx, oracle):
+    # One Qwen3-0.6B layer with the full 151 936-entry vocabulary: the LM-head kernels (streaming form up to 64 rows, its row
+    # tiles of 16, the chunked kernel beyond), the per-row arg-max finish and the decode kernels at batch sizes that are not a
+    # power of two -- every kernel choice that depends on the row count, at the real matrix sizes.  (The full-depth tests
+    # run 1, 4, 64 or 256 rows; the batch-40 attention-order bug, DESIGN.md §2, lived between them.)
+    cfg = pkg.Qwen3Config.qwen3_0_6b()
+    cfg.num_hidden_layers = 1
+    Bmax = 200
+    m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 9, ctx)
+    m.kv_alloc(Bmax + 2, Bmax, 512)
+    om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(9)
+    rng = np.random.default_rng(2)
+    seqs = [rng.integers(0, cfg.vocab_size, int(n)).tolist() for n in rng.integers(1, 40, Bmax)]
+    ids, _ = m.step(list(range(Bmax)), seqs, True, want_logits=False)
+    for s, t in zip(seqs, ids):
+        s.append(int(t))
+    worst = 0.0
+    for B in (1, 3, 15, 16, 17, 31, 33, 40, 48, 63, 64, 65, 100, 127, 128, 129, 200):
+        sub = [int(i) for i in rng.permutation(Bmax)[:B]]
+        got, lg = m.step(sub, [seqs[i] for i in sub], False, want_logits=True)
+        pick = sub if B <= 8 else [sub[0], sub[B // 2], sub[-1], sub[min(B - 1, 16)], sub[min(B - 1, 39)]]
+        rid, rlg = oracle_rows(om, [seqs[i] for i in pick])
+        rows = [sub.index(i) for i in pick]
+        worst = max(worst, check_rows(f"0.6B x 1 layer, full vocabulary, {B} decode rows", got[rows], lg[rows], rid, rlg))
+        assert np.isfinite(lg).all() and (got == lg.argmax(axis=1)).mean() > 0.99  # every row's id is (a) max of its logits
+        for i, t in zip(sub, got):
+            seqs[i].append(int(t))
+    print(f"[parity] odd batch sizes, worst {worst:.3e}")
+    m.close()
