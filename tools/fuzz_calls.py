@@ -57,6 +57,9 @@ cases = [
     ("tiny, long contexts (many KV blocks, split-KV decode with 2..64 parts)", T(), 64, 4, 512, 2, [500, 700, 1023, 1024, 1025, 2000, 3000], {}),
     ("tiny hd 128 gqa 8, long contexts", T(head_dim=128, num_attention_heads=8, num_key_value_heads=1), 64, 5, 1024, 2,
      [257, 511, 513, 1500, 2500], {}),
+    ("32B layer shapes x 1 (10- and 13-wave streaming launches at 17..64 rows)", T(hidden_size=5120, head_dim=128, num_attention_heads=64,
+                                                                                  num_key_value_heads=8, intermediate_size=25600, vocab_size=1024, num_hidden_layers=1),
+     80, 72, 256, 24, [1, 2, 3, 5], {}),
     ("0.6B layer shapes x 2, no fused path", T(hidden_size=1024, head_dim=128, num_attention_heads=16, num_key_value_heads=8,
                                               intermediate_size=3072, vocab_size=2048), 64, 28, 128, 6, short + [255, 257], {"no_fused": 1}),
 ]
@@ -113,7 +116,7 @@ for name, cfg, NB, MS, mbt, max_new, menu, opts in cases:
         continue
     for seed in (range(first_seed, first_seed + 1) if random_n else range(100, 100 + n_seeds)):
         t0 = time.time()
-        iters = 24 if "8B" in name else (50 if "long" in name else (60 if random_n else 120))
+        iters = 60 if "8B" in name else 50 if "32B" in name else (50 if "long" in name else (60 if random_n else 120))
         om = CachedOracle(oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(seed))
         res, errs = [None] * tp, []
         lock = threading.Lock()
