@@ -7,6 +7,9 @@ import os
 import sys
 import time
 
+# rank / context threads each get an OpenMP team of their own inside the oracle; with the default active wait policy the idle
+# teams spin against the working one (a 2 s case took 6 minutes with four threads)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nano_vllm_candle_amd as pkg  # noqa: E402
 from oracle import oracle  # noqa: E402  (a tool, not the product: the oracle is the checker here)
@@ -20,6 +23,11 @@ tp = 1
 if "--tp" in sys.argv:
     i = sys.argv.index("--tp")
     tp = int(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
+concurrent = 0  # N independent contexts + models driven by N threads at once (same case, different seeds)
+if "--concurrent" in sys.argv:
+    i = sys.argv.index("--concurrent")
+    concurrent = int(sys.argv[i + 1])
     del sys.argv[i:i + 2]
 only = None
 if "--only" in sys.argv:
@@ -108,6 +116,41 @@ class CachedOracle:
 
 bad = 0
 group = 0
+if concurrent:
+    lock = threading.Lock()
+    for name, cfg, NB, MS, mbt, max_new, menu, opts in cases:
+        if (only and only not in name) or "8B" in name or "32B" in name:
+            continue
+        t0 = time.time()
+        res, errs = [None] * concurrent, []
+
+        def cworker(j):
+            try:
+                c = pkg.Context(0)
+                seed = 300 + j
+                m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed, c)
+                for k, v in opts.items():
+                    m.set_option(k, v)
+                m.kv_alloc(NB, MS, mbt)
+                om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(seed)
+                res[j] = random_calls(m, om, cfg, seed, 60, NB, MS, max_new=max_new, lens_menu=menu, lock=lock)
+                m.close()
+                c.close()
+            except BaseException as e:  # noqa: BLE001
+                errs.append(f"thread {j}: {type(e).__name__}: {str(e)[:300]}")
+
+        th = [threading.Thread(target=cworker, args=(j,), daemon=True) for j in range(concurrent)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=900)
+        if errs or any(r is None for r in res):
+            bad += 1
+            print(f"FAIL {name} x {concurrent} concurrent: {errs[:2] or 'a thread hung'}", flush=True)
+        else:
+            print(f"ok   {name} x {concurrent} concurrent: calls {[r[0] for r in res]}, worst {max(r[1] for r in res):.2e}, {time.time() - t0:.1f} s", flush=True)
+    print("failures:", bad)
+    sys.exit(1 if bad else 0)
 for name, cfg, NB, MS, mbt, max_new, menu, opts in cases:
     if only and only not in name:
         continue
