@@ -224,9 +224,10 @@ struct AttnArgs {
     const int* tile_last = nullptr;    // optional (prefill kernel): position of the tile's last row, -1 for an empty tile;
                                        // saves the kernel a chain of dependent metadata loads per workgroup
     const int* pos = nullptr;          // [rows]
-    // load balance (decode): tile_order[rank] = tile index, longest context first; the kernel walks it forwards
-    // in even 256-workgroup rounds and backwards in odd ones so that co-resident workgroups (ids i and i+256
-    // share a CU when two fit) pair a long sequence with a short one.  nullptr = launch order.
+    // load balance (decode): tile_order[rank] = tile index, longest context first; a grid row (one kv head) walks it
+    // forwards when the row starts in an even 256-workgroup round and backwards when in an odd one, so that co-resident
+    // workgroups (ids i and i+256 share a CU when two fit) pair a long sequence with a short one.  The direction is per
+    // ROW: every row must visit every tile exactly once whatever the batch size.  nullptr = launch order.
     const int* tile_order = nullptr;
     int nh_l = 0, gqa = 1;
     bf16_bits* out_hi = nullptr;       // [rows][nh_l*hd]

@@ -68,6 +68,11 @@ cases = [
     ("32B layer shapes x 1 (10- and 13-wave streaming launches at 17..64 rows)", T(hidden_size=5120, head_dim=128, num_attention_heads=64,
                                                                                   num_key_value_heads=8, intermediate_size=25600, vocab_size=1024, num_hidden_layers=1),
      80, 72, 256, 24, [1, 2, 3, 5], {}),
+    ("heavy weight statistics (profile 1), 0.6B layer shapes x 2, 24-bit V", T(hidden_size=1024, head_dim=128, num_attention_heads=16,
+                                                                              num_key_value_heads=8, intermediate_size=3072, vocab_size=2048),
+     64, 28, 128, 6, short + [100, 255, 257], {"_profile": 1, "kv_v_bits": 24}),
+    ("heavy weight statistics (profile 1), tiny hd 128", T(head_dim=128, num_attention_heads=4, num_key_value_heads=2), 40, 20, 64, 5,
+     short + [255, 257], {"_profile": 1}),
     ("0.6B layer shapes x 2, no fused path", T(hidden_size=1024, head_dim=128, num_attention_heads=16, num_key_value_heads=8,
                                               intermediate_size=3072, vocab_size=2048), 64, 28, 128, 6, short + [255, 257], {"no_fused": 1}),
 ]
@@ -160,7 +165,7 @@ for name, cfg, NB, MS, mbt, max_new, menu, opts in cases:
     for seed in (range(first_seed, first_seed + 1) if random_n else range(100, 100 + n_seeds)):
         t0 = time.time()
         iters = 60 if "8B" in name else 50 if "32B" in name else (50 if "long" in name else (60 if random_n else 120))
-        om = CachedOracle(oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(seed))
+        om = CachedOracle(oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(seed, opts.get("_profile", 0)))
         res, errs = [None] * tp, []
         lock = threading.Lock()
         group += 1
@@ -168,9 +173,10 @@ for name, cfg, NB, MS, mbt, max_new, menu, opts in cases:
         def worker(rank):
             try:
                 c = ctx if tp == 1 else pkg.Context(0, tp_rank=rank, tp_size=tp, loopback_group=f"fz{group}")
-                m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed, c)
+                m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed, c, profile=opts.get("_profile", 0))
                 for k, v in opts.items():
-                    m.set_option(k, v)
+                    if not k.startswith("_"):
+                        m.set_option(k, v)
                 m.kv_alloc(NB, MS, mbt)
                 res[rank] = random_calls(m, om, cfg, seed, iters, NB, MS, max_new=max_new, lens_menu=menu, lock=lock if tp > 1 else None)
                 m.close()
