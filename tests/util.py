@@ -27,7 +27,7 @@ def bf16_round(a):
 LOGITS_TOL = 1e-3  # BASELINE.json north_star: logits within 1e-3 relative of the reference CPU path
 
 
-def random_calls(m, om, cfg, seed, iters, NB, MS, lock=None, max_new=2, lens_menu=None):
+def random_calls(m, om, cfg, seed, iters, NB, MS, lock=None, max_new=2, lens_menu=None, tol=LOGITS_TOL):
     """Drive model m (pool of NB blocks, MS sequence slots) with a seeded random caller and check every call against the
     oracle model om (its dense re-forward of each sequence on its own); returns (calls made, worst logits error).
     lock: serialises the oracle calls when several rank threads drive the same sequence (tensor-parallel test)."""
@@ -56,13 +56,13 @@ def random_calls(m, om, cfg, seed, iters, NB, MS, lock=None, max_new=2, lens_men
             if got_lg is not None:
                 e = row_rel_err(got_lg[k:k + 1], rlg)
                 worst = max(worst, e)
-                assert e < LOGITS_TOL, (cur_op[0], len(ids), sid, len(live[sid]), e)
+                assert e < tol, (cur_op[0], len(ids), sid, len(live[sid]), e)
             gid = int(got_ids[k])
             if gid != int(rid[0]):
                 # two logits closer than twice the tolerance may swap places: a tie, not an error ("ids exact where the
                 # margin is clear"); the caller goes on with the GPU's choice, as the device-fed decode already has
                 gap = float(rlg[0, int(rid[0])] - rlg[0, gid]) / float(np.abs(rlg).max())
-                assert 0.0 <= gap <= 2 * LOGITS_TOL, (cur_op[0], len(ids), sid, len(live[sid]), gid, int(rid[0]), gap)
+                assert 0.0 <= gap <= 2 * tol, (cur_op[0], len(ids), sid, len(live[sid]), gid, int(rid[0]), gap)
                 ties.append(gap)
             live[sid].append(gid)
 

@@ -70,9 +70,11 @@ cases = [
      80, 72, 256, 24, [1, 2, 3, 5], {}),
     ("heavy weight statistics (profile 1), 0.6B layer shapes x 2, 24-bit V", T(hidden_size=1024, head_dim=128, num_attention_heads=16,
                                                                               num_key_value_heads=8, intermediate_size=3072, vocab_size=2048),
-     64, 28, 128, 6, short + [100, 255, 257], {"_profile": 1, "kv_v_bits": 24}),
+     64, 28, 128, 6, short + [100, 255, 257], {"_profile": 1, "kv_v_bits": 24, "_tol": 2e-3}),
     ("heavy weight statistics (profile 1), tiny hd 128", T(head_dim=128, num_attention_heads=4, num_key_value_heads=2), 40, 20, 64, 5,
-     short + [255, 257], {"_profile": 1}),
+     short + [255, 257], {"_profile": 1, "_tol": 2e-3}),
+    # (_tol 2e-3: the bound tests/test_stress_gpu.py holds the heavy profile to with the default cache; on these two-layer,
+    # small-vocabulary models single rows reach 1.1e-3 even with 24-bit V -- K's f16 rounding, tools/numerics_study.py)
     ("0.6B layer shapes x 2, no fused path", T(hidden_size=1024, head_dim=128, num_attention_heads=16, num_key_value_heads=8,
                                               intermediate_size=3072, vocab_size=2048), 64, 28, 128, 6, short + [255, 257], {"no_fused": 1}),
 ]
@@ -178,7 +180,8 @@ for name, cfg, NB, MS, mbt, max_new, menu, opts in cases:
                     if not k.startswith("_"):
                         m.set_option(k, v)
                 m.kv_alloc(NB, MS, mbt)
-                res[rank] = random_calls(m, om, cfg, seed, iters, NB, MS, max_new=max_new, lens_menu=menu, lock=lock if tp > 1 else None)
+                res[rank] = random_calls(m, om, cfg, seed, iters, NB, MS, max_new=max_new, lens_menu=menu, lock=lock if tp > 1 else None,
+                                         tol=opts.get("_tol", 1e-3))
                 m.close()
                 if tp > 1:
                     c.close()
