@@ -31,6 +31,7 @@ int nvllm_profile_read(nvllm_model* m, double* total_ms, int64_t* launches);
 /* Per-model options (A/B runs, tests, and two deployment knobs).  The library reads no environment variable.
  *   "kv_v_bits" (16 | 24; takes effect at the next nvllm_kv_alloc): 24 keeps V as f16 + a bf8 residual byte (13..14 bits;
  *       V bytes x1.5; head_dim 128 only) -- the knob for holding the 1e-3 logits bar on heavy-tailed checkpoints;
+ *   "kv_k_bits" (16 | 24; at the next nvllm_kv_alloc, which refuses it without "kv_v_bits" = 24): the same for K;
  *   "oneshot_allreduce" (0 | 1; at the next nvllm_kv_alloc, every rank alike): one-shot all-reduce for decode messages;
  *       "oneshot_spins": bound of its wait kernel's poll; "oneshot_skip_push": test hook (this rank skips N pushes);
  *   "stream_combine" (default 0): let the fused forward use the streaming GEMM's in-launch split-K combine epilogues (fewer

@@ -443,6 +443,7 @@ struct nvllm_model {
     int num_blocks = 0, max_seqs = 0, max_blocks = 0, max_rows = 0;
     std::vector<f16_bits*> kcache, vcache;
     std::vector<uint8_t*> vlocache;  // 24-bit V (opt_kv_v_bits == 24): one residual byte per V element, else empty
+    std::vector<uint8_t*> klocache;  // 24-bit K (opt_kv_k_bits == 24, only with 24-bit V): the same for K
     std::vector<int> free_blocks, free_slots;
     std::unordered_map<int64_t, SeqState> seqs;
     int* d_block_tables = nullptr;
@@ -463,6 +464,7 @@ struct nvllm_model {
     int opt_stream_combine = 0;
     int opt_oneshot_allreduce = 0;  // TP decode: one-shot all-reduce instead of the communicator's (set before kv_alloc; opt-in)
     int opt_kv_v_bits = 16;            // 24: V as f16 + e5m2 residual (13..14 significant bits, V bytes x1.5); read at kv_alloc
+    int opt_kv_k_bits = 16;            // 24: K likewise (needs kv_v_bits = 24: K/V bytes x1.5 together); read at kv_alloc
     int opt_oneshot_skip_push = 0;     // test hook: this rank "forgets" its next N pushes (the give-up path of its peers' waits)
     int opt_oneshot_spins = 20000000;  // bound of the one-shot wait kernel's poll (~ seconds): a missing peer is an error code
     int opt_no_fused = 0, opt_no_xpack = 0, opt_no_rowpar = 0;  // A/B switches (nvllm_debug_set_option): force the generic paths
@@ -611,7 +613,8 @@ static void free_kv(nvllm_model* m) {
     for (auto p : m->kcache) (void)hipFree(p);
     for (auto p : m->vcache) (void)hipFree(p);
     for (auto p : m->vlocache) (void)hipFree(p);
-    m->kcache.clear(); m->vcache.clear(); m->vlocache.clear();
+    for (auto p : m->klocache) (void)hipFree(p);
+    m->kcache.clear(); m->vcache.clear(); m->vlocache.clear(); m->klocache.clear();
     void* ptrs[] = {m->d_block_tables, m->d_ids, m->d_pos, m->d_slot, m->d_tile_row0, m->d_tile_nrows, m->d_tile_slot,
                     m->d_last_rows, m->d_tile_order, m->d_tile_last, m->d_group_order, m->resid, m->slabs, m->qbuf, m->logits, m->d_maxval, m->red, m->xh, m->xl, m->xh2, m->xl2, m->ctxh, m->ctxl, m->ssqA, m->ssqB, m->d_next,
                     m->part_val, m->part_idx, m->argmax_scratch, m->attn_po, m->attn_pml, m->tap_h, m->tap_res, m->cosv, m->sinv, m->tickets, m->qkv_out, m->d_keys, m->d_temps};
@@ -868,15 +871,21 @@ extern "C" int nvllm_kv_alloc(nvllm_model* m, int num_blocks, int block_size, in
     m->max_blocks = std::max(1, std::min(num_blocks, by_pos));
     const size_t per_layer = (size_t)num_blocks * m->kv_l * kBlockTokens * m->hd;
     if (m->opt_kv_v_bits == 24 && m->hd != 128) return fail(ctx, NVLLM_EINVAL, "kv_v_bits = 24 needs head_dim 128");
+    if (m->opt_kv_k_bits == 24 && m->opt_kv_v_bits != 24) return fail(ctx, NVLLM_EINVAL, "kv_k_bits = 24 needs kv_v_bits = 24 as well");
     m->kcache.assign(m->L, nullptr);
     m->vcache.assign(m->L, nullptr);
     if (m->opt_kv_v_bits == 24) m->vlocache.assign(m->L, nullptr);
+    if (m->opt_kv_k_bits == 24) m->klocache.assign(m->L, nullptr);
     for (int l = 0; l < m->L; ++l) {
         HIPCHK(ctx, hipMalloc((void**)&m->kcache[l], per_layer * 2));
         HIPCHK(ctx, hipMalloc((void**)&m->vcache[l], per_layer * 2));
         if (!m->vlocache.empty()) {
             HIPCHK(ctx, hipMalloc((void**)&m->vlocache[l], per_layer));
             HIPCHK(ctx, hipMemsetAsync(m->vlocache[l], 0, per_layer, ctx->stream));
+        }
+        if (!m->klocache.empty()) {
+            HIPCHK(ctx, hipMalloc((void**)&m->klocache[l], per_layer));
+            HIPCHK(ctx, hipMemsetAsync(m->klocache[l], 0, per_layer, ctx->stream));
         }
         // zero once: masked lanes multiply P = 0 with whatever the block holds; 0 * finite = 0 needs finite data
         HIPCHK(ctx, hipMemsetAsync(m->kcache[l], 0, per_layer * 2, ctx->stream));
@@ -969,7 +978,8 @@ extern "C" int nvllm_kv_num_free_blocks(const nvllm_model* m) { return m ? (int)
 extern "C" int64_t nvllm_kv_bytes_per_token(const nvllm_model* m) {
     if (!m) return 0;
     const int64_t v_bytes = m->vlocache.empty() ? 2 : 3;  // 24-bit V: + one residual byte per element
-    return (int64_t)m->kv_l * m->hd * (2 + v_bytes) * m->L;
+    const int64_t k_bytes = m->klocache.empty() ? 2 : 3;
+    return (int64_t)m->kv_l * m->hd * (k_bytes + v_bytes) * m->L;
 }
 
 static void release_seq(nvllm_model* m, SeqState& s) {
@@ -1216,6 +1226,7 @@ static int forward_chunk_fused(nvllm_model* m, const FusedPlan& fp, int R, int n
         qa.q_out = m->qbuf; qa.rn = rn;
         qa.kv.k = m->kcache[l]; qa.kv.v = m->vcache[l]; qa.kv.kv_l = m->kv_l; qa.kv.hd = hd;
         qa.kv.vlo = m->vlocache.empty() ? nullptr : m->vlocache[l];
+        qa.kv.klo = m->klocache.empty() ? nullptr : m->klocache[l];
         const bool fuse_qk = qt == 1 && n_tiles == R && !m->opt_no_attn_prologue;
         if (!fuse_qk) PROF(m, PROF_QK, launch_qk_norm_rope_kvwrite(qa, R, s));
         AttnArgs aa;
@@ -1364,6 +1375,7 @@ static int forward_chunk(nvllm_model* m, int R, int n_tiles, int qt, int n_last,
         qa.q_out = m->qbuf;
         qa.kv.k = m->kcache[l]; qa.kv.v = m->vcache[l]; qa.kv.kv_l = m->kv_l; qa.kv.hd = hd;
         qa.kv.vlo = m->vlocache.empty() ? nullptr : m->vlocache[l];
+        qa.kv.klo = m->klocache.empty() ? nullptr : m->klocache[l];
         const bool fuse_qk = qt == 1 && n_tiles == R;  // decode: every q-tile is one row
         int rcg = NVLLM_OK;
         if (t_qkv_fused && !fuse_qk) {
@@ -1878,6 +1890,10 @@ extern "C" int nvllm_debug_set_option(nvllm_model* m, const char* name, int valu
     if (!strcmp(name, "stream_combine")) { m->opt_stream_combine = value; return NVLLM_OK; }
     if (!strcmp(name, "oneshot_allreduce")) { m->opt_oneshot_allreduce = value; return NVLLM_OK; }  // takes effect at the next kv_alloc
     if (!strcmp(name, "oneshot_spins")) { m->opt_oneshot_spins = std::max(1, value); return NVLLM_OK; }
+    if (!strcmp(name, "kv_k_bits")) {  // takes effect at the next kv_alloc (which insists on kv_v_bits = 24 with it)
+        if (value != 16 && value != 24) return fail(m->ctx, NVLLM_EINVAL, "kv_k_bits is 16 or 24");
+        m->opt_kv_k_bits = value; return NVLLM_OK;
+    }
     if (!strcmp(name, "kv_v_bits")) {  // takes effect at the next kv_alloc
         if (value != 16 && value != 24) return fail(m->ctx, NVLLM_EINVAL, "kv_v_bits is 16 or 24");
         m->opt_kv_v_bits = value; return NVLLM_OK;

@@ -154,6 +154,23 @@ __device__ __forceinline__ void store_v24(_Float16* v, uint8_t* vlo, int t_in_bl
     }
 }
 
+// 24-bit K (KvLayout::klo): the same residual byte per K element, two QK^T fragments (head-dim chunks c, c+1 of one 16-token
+// tile) per 16-byte lane slot.  Byte offset inside one (block, kv head) slab of kBlockTokens x hd bytes:
+__device__ __forceinline__ size_t klo_packed_offset(int t_in_block, int d, int hd) {
+    const int tt = t_in_block >> 4, r = t_in_block & 15;
+    const int c = d >> 5, g = (d & 31) >> 3, j = d & 7;
+    return ((size_t)(tt * (hd >> 6) + (c >> 1)) * 64 + (g << 4) + r) * 16 + (size_t)((c & 1) << 3) + j;
+}
+__device__ __forceinline__ void store_k24(_Float16* k, uint8_t* klo, int t_in_block, int d, int hd, float x) {
+    const _Float16 h = f16_sat(x);
+    k[k_packed_offset(t_in_block, d, hd)] = h;
+    if (klo) {
+        const float xc = fminf(fmaxf(x, -65504.f), 65504.f);
+        const uint32_t b = __builtin_bit_cast(uint16_t, (_Float16)(xc - (float)h));
+        klo[klo_packed_offset(t_in_block, d, hd)] = (uint8_t)((b + 0x7Fu + ((b >> 8) & 1u)) >> 8);
+    }
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 

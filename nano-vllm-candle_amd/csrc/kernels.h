@@ -153,6 +153,7 @@ struct KvLayout {
     f16_bits* k = nullptr;  // [num_blocks][kv_l][16 tiles][hd/32][64 lanes][8] f16 (QK^T A-fragment packed)
     f16_bits* v = nullptr;  // [num_blocks][kv_l][8 tiles][hd/16][64 lanes][8] f16 (PV A-fragment packed)
     uint8_t* vlo = nullptr; // optional 24-bit V: e5m2 rounding residual of every V element, same element order (1 byte each)
+    uint8_t* klo = nullptr; // optional 24-bit K (only together with vlo): the same for K (device_common.h: klo_packed_offset)
     int kv_l = 0, hd = 0;
 };
 struct QkvArgs {

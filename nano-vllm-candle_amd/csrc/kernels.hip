@@ -1525,9 +1525,11 @@ __global__ void __launch_bounds__(256) qk_norm_rope_kvwrite_kernel(QkvArgs a) {
         } else if (act) {
             const int kh = hh - a.nh_l;
             const int blk = a.block_tables[(size_t)a.slot[row] * a.max_blocks + (pos >> 8)];
-            _Float16* k = reinterpret_cast<_Float16*>(a.kv.k) + (size_t)(blk * kv_l + kh) * kBlockTokens * hd;
-            k[k_packed_offset(pos & 255, lane, hd)] = f16_sat(y1);
-            k[k_packed_offset(pos & 255, lane + half, hd)] = f16_sat(y2);
+            const size_t ko = (size_t)(blk * kv_l + kh) * kBlockTokens * hd;
+            _Float16* k = reinterpret_cast<_Float16*>(a.kv.k) + ko;
+            uint8_t* klo = a.kv.klo ? a.kv.klo + ko : nullptr;
+            store_k24(k, klo, pos & 255, lane, hd, y1);
+            store_k24(k, klo, pos & 255, lane + half, hd, y2);
         }
     } else if (act) {  // v head: plain copy into the packed layout
         const int kh = hh - a.nh_l - kv_l;
@@ -1559,9 +1561,8 @@ __global__ void __launch_bounds__(256) kv_write_plain_kernel(const float* __rest
     const int blk = bt[(size_t)slot[row] * max_blocks + (p >> 8)];
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int kh = i / kv.hd, d = i - kh * kv.hd;
-        _Float16* kd = reinterpret_cast<_Float16*>(kv.k) + (size_t)(blk * kv.kv_l + kh) * kBlockTokens * kv.hd;
-        kd[k_packed_offset(p & 255, d, kv.hd)] = f16_sat(k[(size_t)row * n + i]);
         const size_t vo = (size_t)(blk * kv.kv_l + kh) * kBlockTokens * kv.hd;
+        store_k24(reinterpret_cast<_Float16*>(kv.k) + vo, kv.klo ? kv.klo + vo : nullptr, p & 255, d, kv.hd, k[(size_t)row * n + i]);
         store_v24(reinterpret_cast<_Float16*>(kv.v) + vo, kv.vlo ? kv.vlo + vo : nullptr, p & 255, d, kv.hd, v[(size_t)row * n + i]);
     }
 }
@@ -1595,9 +1596,13 @@ __device__ uint4 g_attn_dummy_tile[1024];
 
 // VLO: 24-bit V (KvLayout::vlo): every V fragment comes with 8 residual bytes per lane (a 512-byte wave-load); shifted into
 // the high byte they ARE the residuals' f16 bit patterns, which a second P.V MFMA adds (the kernel is HBM-bound: V bytes x1.5)
-template <int HD, int QT, int NWV, bool FUSED, bool VLO = false>
+// VLO: 0 = 16-bit cache, 1 = 24-bit V, 2 = 24-bit K and V (KvLayout::klo too: four more 1 KiB wave-loads per tile, one bf8 MFMA
+// per QK^T fragment against q in bf8)
+template <int HD, int QT, int NWV, bool FUSED, int VLO = 0>
 __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1) attn_paged_kernel(AttnArgs a) {
     constexpr int DC = HD / 32, DT = HD / 16, DL = VLO ? DT / 2 : 1;  // DL: 1 KiB residual fragments per tile (two PV fragments each)
+    constexpr bool KLO = VLO == 2;
+    constexpr int RL = DL + (KLO ? DC : 0);  // residual registers per tile: V's DL, then K's [token half][DC / 2]
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* ml = reinterpret_cast<float*>(smem_raw);                          // [NWV][QT][2][16]
     f32x4* obuf = reinterpret_cast<f32x4*>(smem_raw + NWV * QT * 2 * 16 * 4);  // [NWV][QT][DT][64]
@@ -1645,7 +1650,7 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1
     const _Float16* vbase = reinterpret_cast<const _Float16*>(a.kv.v);
     const uint8_t* vlobase = a.kv.vlo;
     // one 32-token KV tile (tokens tb..tb+31 of block blk): 2*DC K fragments + DT V fragments, 16 KiB in 1 KiB wave-loads
-    auto load_tile_at = [&](int blk, int tb, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint4 (&vl)[DL]) {
+    auto load_tile_at = [&](int blk, int tb, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint4 (&vl)[RL]) {
         auto ld = [&](const _Float16* p) -> uint4 { return ld_stream16(p); };
         // packed K: the two 16-token tiles of this 32-token step are 2*DC contiguous 1 KiB fragments
         const _Float16* kb = kbase + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 4) * (DC * 512) + lane * 8;
@@ -1662,14 +1667,19 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1
 #pragma unroll
             for (int d = 0; d < DL; ++d) vl[d] = ld_stream16(vlb + d * 1024);
         }
+        if constexpr (KLO) {
+            const uint8_t* klb = a.kv.klo + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 4) * ((DC / 2) * 1024) + lane * 16;
+#pragma unroll
+            for (int i = 0; i < DC; ++i) vl[DL + i] = ld_stream16(klb + i * 1024);
+        }
     };
-    auto load_tile = [&](int kt, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint4 (&vl)[DL]) {
+    auto load_tile = [&](int kt, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint4 (&vl)[RL]) {
         const int T0 = kt << 5;
         load_tile_at(bt[T0 >> 8], T0 & 255, ka, kb2, vf, vl);
     };
     // tile kt if it exists (kt < t_end), else the shared dummy tile (same instruction stream, no K/V traffic)
     // avoid: a tile that must not be touched yet (see the fused prologue): its 32-token neighbour in the block is read instead
-    auto load_tile_or_dummy = [&](int kt, int t_end_, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint4 (&vl)[DL], int avoid = -1) {
+    auto load_tile_or_dummy = [&](int kt, int t_end_, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint4 (&vl)[RL], int avoid = -1) {
         const bool real = kt < t_end_;
         const int T0 = min(kt, t_end_ - 1) << 5;
         const int blk = bt[T0 >> 8], tb = (T0 & 255) ^ (kt == avoid ? 32 : 0);
@@ -1689,10 +1699,16 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1
 #pragma unroll
             for (int d = 0; d < DL; ++d) vl[d] = ld_stream16(vlb + d * 1024);
         }
+        if constexpr (KLO) {
+            const uint8_t* klb = real ? a.kv.klo + (size_t)(blk * kv_l + kh) * kBlockTokens * HD + (size_t)(tb >> 4) * ((DC / 2) * 1024) + lane * 16
+                                      : reinterpret_cast<const uint8_t*>(g_attn_dummy_tile) + lane * 16;
+#pragma unroll
+            for (int i = 0; i < DC; ++i) vl[DL + i] = ld_stream16(klb + i * 1024);
+        }
     };
     // decode register sets (QT == 1): two 32-token tiles (32 KiB) of this wave are in flight at any time
     uint4 kaA[DC], kbA[DC], vfA[DT], kaB[DC], kbB[DC], vfB[DT];
-    uint4 vlA[DL], vlB[DL];
+    uint4 vlA[RL], vlB[RL];
     f16x8 qh[QT][DC], ql[QT][DC];
     if constexpr (FUSED) {
         // Decode, fused prologue (replaces a separate launch): this workgroup is the only consumer of q heads
@@ -1781,10 +1797,11 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1
             if (owner && act) {
                 const int blk = bt[pos >> 8];
                 const float n1 = (kx1 * krinv) * knw1, n2 = (kx2 * krinv) * knw2;
-                _Float16* k = reinterpret_cast<_Float16*>(a.kv.k) + (size_t)(blk * kv_l + kh) * kBlockTokens * HD;
-                k[k_packed_offset(pos & 255, lane, HD)] = f16_sat(n1 * kc - n2 * ks);
-                k[k_packed_offset(pos & 255, lane + half, HD)] = f16_sat(n2 * kc + n1 * ks);
                 const size_t vo = (size_t)(blk * kv_l + kh) * kBlockTokens * HD;
+                _Float16* k = reinterpret_cast<_Float16*>(a.kv.k) + vo;
+                uint8_t* klo = KLO ? a.kv.klo + vo : nullptr;
+                store_k24(k, klo, pos & 255, lane, HD, n1 * kc - n2 * ks);
+                store_k24(k, klo, pos & 255, lane + half, HD, n2 * kc + n1 * ks);
                 _Float16* v = reinterpret_cast<_Float16*>(a.kv.v) + vo;
                 uint8_t* vlo = VLO ? a.kv.vlo + vo : nullptr;
                 store_v24(v, vlo, pos & 255, lane, HD, vx1 * ri);
@@ -1844,6 +1861,21 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1
             }
     }
 
+    // 24-bit K: q once more as bf8 (the B operand of the residual MFMA; two mantissa bits leave that 2^-12-sized term 12 % accurate)
+    [[maybe_unused]] long q8[QT][DC];
+    if constexpr (KLO) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int c = 0; c < DC; ++c) {
+                int w0 = 0, w1 = 0;
+                w0 = __builtin_amdgcn_cvt_pk_bf8_f32((float)qh[t][c][0], (float)qh[t][c][1], w0, false);
+                w0 = __builtin_amdgcn_cvt_pk_bf8_f32((float)qh[t][c][2], (float)qh[t][c][3], w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_bf8_f32((float)qh[t][c][4], (float)qh[t][c][5], w1, false);
+                w1 = __builtin_amdgcn_cvt_pk_bf8_f32((float)qh[t][c][6], (float)qh[t][c][7], w1, true);
+                q8[t][c] = (long)(((unsigned long long)(unsigned)w1 << 32) | (unsigned)w0);
+            }
+    }
     f32x4 o[QT][DT];
     float m[QT], lsum[QT];
 #pragma unroll
@@ -1854,7 +1886,7 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1
         for (int d = 0; d < DT; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    auto compute_tile = [&](int kt, const uint4 (&ka)[DC], const uint4 (&kb2)[DC], const uint4 (&vf)[DT], const uint4 (&vl)[DL]) {
+    auto compute_tile = [&](int kt, const uint4 (&ka)[DC], const uint4 (&kb2)[DC], const uint4 (&vf)[DT], const uint4 (&vl)[RL]) {
         const int T0 = kt << 5;
         const int tokA = T0 + grp * 4, tokB = T0 + 16 + grp * 4;
 #pragma unroll
@@ -1868,6 +1900,13 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1
                 sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, ql[t][c], sa, 0, 0, 0);
                 sb = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, qh[t][c], sb, 0, 0, 0);
                 sb = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb, ql[t][c], sb, 0, 0, 0);
+                if constexpr (KLO) {  // the K residual bytes are bf8 numbers: A operands as they are
+                    const uint4 pa = vl[DL + (c >> 1)], pb = vl[DL + DC / 2 + (c >> 1)];
+                    const unsigned long long la = (c & 1) ? ((unsigned long long)pa.w << 32) | pa.z : ((unsigned long long)pa.y << 32) | pa.x;
+                    const unsigned long long lb = (c & 1) ? ((unsigned long long)pb.w << 32) | pb.z : ((unsigned long long)pb.y << 32) | pb.x;
+                    sa = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8((long)la, q8[t][c], sa, 0, 0, 0);
+                    sb = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8((long)lb, q8[t][c], sb, 0, 0, 0);
+                }
             }
             float mt = -1e30f;
 #pragma unroll
@@ -1948,7 +1987,7 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1
             }
             // refills past the end: the shared dummy tile (fused kernel: the one the model runs); the plain-q variant
             // (fine-seam op, tuning bench) keeps the clamped re-read -- the extra address selects would spill it
-            auto refill = [&](int kt_next, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint4 (&vl)[DL]) {
+            auto refill = [&](int kt_next, uint4 (&ka)[DC], uint4 (&kb2)[DC], uint4 (&vf)[DT], uint4 (&vl)[RL]) {
                 if constexpr (FUSED) load_tile_or_dummy(kt_next, t_end, ka, kb2, vf, vl);
                 else load_tile(min(kt_next, t_end - 1), ka, kb2, vf, vl);
             };
@@ -1963,7 +2002,7 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1
             }
         } else {
             uint4 ka[DC], kb2[DC], vf[DT];
-            uint4 vl[DL];
+            uint4 vl[RL];
             for (int kt = t_begin + wave; kt < t_end; kt += NWV) {
                 load_tile(kt, ka, kb2, vf, vl);
                 compute_tile(kt, ka, kb2, vf, vl);
@@ -2341,7 +2380,7 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(AttnArgs a, int rows)
     }
 }
 
-template <int HD, int QT, int NWV, bool FUSED, bool VLO>
+template <int HD, int QT, int NWV, bool FUSED, int VLO>
 static hipError_t attn_launch_v(const AttnArgs& a, int n_tiles, int grid_z, hipStream_t s) {
     constexpr int DT = HD / 16;
     const size_t lds = (size_t)NWV * QT * 2 * 16 * 4 + (size_t)NWV * QT * DT * 64 * 16;
@@ -2354,9 +2393,12 @@ static hipError_t attn_launch_v(const AttnArgs& a, int n_tiles, int grid_z, hipS
 template <int HD, int QT, int NWV, bool FUSED>
 static hipError_t attn_launch_t(const AttnArgs& a, int n_tiles, int grid_z, hipStream_t s) {
     // 24-bit V (KvLayout::vlo) is served for head_dim 128 only (every Qwen3 size); the pool refuses it otherwise
-    if constexpr (HD == 128) { if (a.kv.vlo) return attn_launch_v<HD, QT, NWV, FUSED, true>(a, n_tiles, grid_z, s); }
-    else if (a.kv.vlo) return hipErrorNotSupported;
-    return attn_launch_v<HD, QT, NWV, FUSED, false>(a, n_tiles, grid_z, s);
+    if (a.kv.klo && !a.kv.vlo) return hipErrorInvalidValue;  // 24-bit K comes with 24-bit V only
+    if constexpr (HD == 128) {
+        if (a.kv.klo) return attn_launch_v<HD, QT, NWV, FUSED, 2>(a, n_tiles, grid_z, s);
+        if (a.kv.vlo) return attn_launch_v<HD, QT, NWV, FUSED, 1>(a, n_tiles, grid_z, s);
+    } else if (a.kv.vlo) return hipErrorNotSupported;
+    return attn_launch_v<HD, QT, NWV, FUSED, 0>(a, n_tiles, grid_z, s);
 }
 
 // prefill: n_tiles (a multiple of 4: every sequence's tile list padded with empty tiles) q-tiles of 2 sub-tiles each

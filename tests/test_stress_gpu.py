@@ -23,13 +23,18 @@ HEAVY = 1
 # byte, V bytes x1.5) removes that term.  Bars: 24-bit V must hold the 1e-3 parity tolerance; the default must stay under
 # DEFAULT_HEAVY_BOUND and is printed, so a drift is on record.
 DEFAULT_HEAVY_BOUND = 2e-3
-V_BITS = [24, 16]
+V_BITS = [48, 24, 16]  # 48: 24-bit K AND V (kv_k_bits = kv_v_bits = 24); 24: 24-bit V; 16: the default cache
+
+
+def set_cache(m, bits):
+    m.set_option("kv_v_bits", 24 if bits >= 24 else 16)
+    m.set_option("kv_k_bits", 24 if bits == 48 else 16)
 
 
 def tol_for(v_bits):
     from tests.util import LOGITS_TOL
 
-    return LOGITS_TOL if v_bits == 24 else DEFAULT_HEAVY_BOUND
+    return LOGITS_TOL if v_bits >= 24 else DEFAULT_HEAVY_BOUND
 
 
 @pytest.fixture(scope="module")
@@ -122,7 +127,7 @@ def test_0_6b_heavy_full_depth_long_contexts_vs_oracle(pkg, ctx, oracle_0_6b_hea
     # prompts {64, 292, 512, 511}, chunked prefill + 8 decode steps
     cfg, om = oracle_0_6b_heavy
     m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx, profile=HEAVY)
-    m.set_option("kv_v_bits", v_bits)
+    set_cache(m, v_bits)
     m.kv_alloc(num_blocks=12, max_seqs=4, max_batched_tokens=512)
     rng = np.random.default_rng(21)
     seqs = [rng.integers(0, cfg.vocab_size, n).tolist() for n in (64, 292, 512, 511)]
@@ -146,7 +151,7 @@ def test_0_6b_heavy_batch64_fused_decode_vs_oracle_sample(pkg, ctx, oracle_0_6b_
     # the bench's own state (64 live sequences, prompts U[64,512] seed 0, fused batch-64 decode) on the heavy profile
     cfg, om = oracle_0_6b_heavy
     m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx, profile=HEAVY)
-    m.set_option("kv_v_bits", v_bits)
+    set_cache(m, v_bits)
     rng = np.random.default_rng(0)
     lens = rng.integers(64, 513, size=64)
     seqs = [rng.integers(0, cfg.vocab_size, size=int(n), dtype=np.uint32).tolist() for n in lens]
@@ -178,7 +183,7 @@ def test_8b_layer_shapes_heavy_batch256_context4096_vs_oracle(pkg, ctx, oracle, 
                                num_attention_heads=32, num_key_value_heads=8, intermediate_size=12288,
                                max_position_embeddings=8192)
     m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 0, ctx, profile=HEAVY)
-    m.set_option("kv_v_bits", v_bits)
+    set_cache(m, v_bits)
     om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(0, HEAVY)
     rng = np.random.default_rng(33)
     lens = [4096, 4000] + rng.integers(3, 200, 254).tolist()
@@ -202,7 +207,7 @@ def test_8b_layer_shapes_heavy_batch256_context4096_vs_oracle(pkg, ctx, oracle, 
     m.close()
 
 
-@pytest.mark.parametrize("oneshot,v_bits", [(0, 24), (1, 24), (0, 16)])
+@pytest.mark.parametrize("oneshot,v_bits", [(0, 48), (0, 24), (1, 24), (0, 16)])
 def test_32b_layer_shapes_heavy_tp8_shards_vs_oracle(pkg, oracle, oneshot, v_bits):
     # one layer at the Qwen3-32B shapes, TP = 8 through the loopback communicator, heavy profile: massive activations cross
     # the two all-reduces per layer as f32 partials (and, oneshot = 1, the device-side one-shot form)
@@ -219,7 +224,7 @@ def test_32b_layer_shapes_heavy_tp8_shards_vs_oracle(pkg, oracle, oneshot, v_bit
             c = pkg.Context(0, tp_rank=rank, tp_size=tp, loopback_group=f"g32b_heavy_{oneshot}_{v_bits}")
             mm = pkg.Qwen3ForCausalLM.from_synthetic(cfg, seed=0, ctx=c, profile=HEAVY)
             mm.set_option("oneshot_allreduce", oneshot)
-            mm.set_option("kv_v_bits", v_bits)
+            set_cache(mm, v_bits)
             mm.kv_alloc(len(seqs) + 4, len(seqs), 1024)
             my = [list(s) for s in seqs]
             out = []
@@ -265,11 +270,11 @@ def test_24_bit_v_cache_paths_on_a_small_model(pkg, ctx, oracle):
     om = oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(3)
     rng = np.random.default_rng(24)
     worst = {}
-    for bits in (24, 16):
+    for bits in (48, 24, 16):
         m = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 3, ctx)
-        m.set_option("kv_v_bits", bits)
+        set_cache(m, bits)
         m.kv_alloc(num_blocks=12, max_seqs=4, max_batched_tokens=128)
-        assert m.kv_bytes_per_token == cfg.num_key_value_heads * cfg.head_dim * (5 if bits == 24 else 4) * cfg.num_hidden_layers
+        assert m.kv_bytes_per_token == cfg.num_key_value_heads * cfg.head_dim * {48: 6, 24: 5, 16: 4}[bits] * cfg.num_hidden_layers
         rng = np.random.default_rng(24)
         seqs = [rng.integers(0, cfg.vocab_size, n).tolist() for n in (250, 37, 5)]  # 250 -> crosses 256 while decoding
         sids = [0, 1, 2]
@@ -296,8 +301,8 @@ def test_24_bit_v_cache_paths_on_a_small_model(pkg, ctx, oracle):
         worst[bits] = w
         assert w < LOGITS_TOL, (bits, w)
         m.close()
-    print(f"[stress] small model, worst logits error: 24-bit V {worst[24]:.3e}, 16-bit V {worst[16]:.3e}")
-    assert worst[24] < worst[16] * 1.2
+    print(f"[stress] small model, worst logits error: 24-bit K+V {worst[48]:.3e}, 24-bit V {worst[24]:.3e}, 16-bit {worst[16]:.3e}")
+    assert worst[24] < worst[16] * 1.2 and worst[48] < worst[24] * 1.2
     m64 = pkg.Qwen3ForCausalLM.from_synthetic(pkg.Qwen3Config.tiny(), 0, ctx)  # head_dim 64
     m64.set_option("kv_v_bits", 24)
     with pytest.raises(pkg._lib.NvllmError) as e:
@@ -306,3 +311,9 @@ def test_24_bit_v_cache_paths_on_a_small_model(pkg, ctx, oracle):
     with pytest.raises(pkg._lib.NvllmError):
         m64.set_option("kv_v_bits", 20)
     m64.close()
+    mk = pkg.Qwen3ForCausalLM.from_synthetic(cfg, 3, ctx)  # 24-bit K without 24-bit V: refused at kv_alloc
+    mk.set_option("kv_k_bits", 24)
+    with pytest.raises(pkg._lib.NvllmError) as e:
+        mk.kv_alloc(4, 2, 64)
+    assert e.value.code == pkg._lib.EINVAL
+    mk.close()

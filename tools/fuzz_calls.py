@@ -71,6 +71,9 @@ cases = [
     ("heavy weight statistics (profile 1), 0.6B layer shapes x 2, 24-bit V", T(hidden_size=1024, head_dim=128, num_attention_heads=16,
                                                                               num_key_value_heads=8, intermediate_size=3072, vocab_size=2048),
      64, 28, 128, 6, short + [100, 255, 257], {"_profile": 1, "kv_v_bits": 24, "_tol": 2e-3}),
+    ("heavy weight statistics (profile 1), 0.6B layer shapes x 2, 24-bit K and V", T(hidden_size=1024, head_dim=128, num_attention_heads=16,
+                                                                                    num_key_value_heads=8, intermediate_size=3072, vocab_size=2048),
+     64, 28, 128, 6, short + [100, 255, 257], {"_profile": 1, "kv_v_bits": 24, "kv_k_bits": 24}),
     ("heavy weight statistics (profile 1), tiny hd 128", T(head_dim=128, num_attention_heads=4, num_key_value_heads=2), 40, 20, 64, 5,
      short + [255, 257], {"_profile": 1, "_tol": 2e-3}),
     # (_tol 2e-3: the bound tests/test_stress_gpu.py holds the heavy profile to with the default cache; on these two-layer,
