@@ -210,7 +210,8 @@ OQ3_API void oq3_rope_apply(float* x, int B, int heads, int T, int hd, float bas
  * in a logits error can be measured on the CPU at full model size (tools/numerics_study.py).
  * bit 0: K -> f16, bit 1: V -> f16, bit 2: unnormalised P = exp(s - max) -> f16, bit 3: K -> bf16, bit 4: V -> bf16,
  * bit 5: K -> f16 hi + f16 lo (22 bits), bit 6: V -> f16 hi + f16 lo, bit 7: P -> bf16 hi + bf16 lo,
- * bit 8: V -> f16 hi + e5m2 lo (the residual's f16 bits cut to their top byte, round to nearest even): 24-bit V. */
+ * bit 8: V -> f16 hi + e5m2 lo (the residual's f16 bits cut to their top byte, round to nearest even): 24-bit V,
+ * bit 9: K -> f16 hi + e5m2 lo: 24-bit K. */
 static int g_study = 0;
 OQ3_API void oq3_set_study(int flags) { g_study = flags; }
 static float study_f16(float x) {
@@ -247,10 +248,13 @@ OQ3_API void oq3_attention(const float* q, const float* k, const float* v, int B
     const float scale = powf((float)hd, -0.5f); /* qwen3.rs:134 */
     const int rep = nh / kv;
     float *ks = NULL, *vs = NULL;
-    if (g_study & (1 | 8 | 32)) {
+    if (g_study & (1 | 8 | 32 | 512)) {
         const size_t n = (size_t)B * kv * T * hd;
         ks = (float*)malloc(sizeof(float) * n);
-        for (size_t i = 0; i < n; ++i) ks[i] = study_round(k[i], g_study & 1, g_study & 8, g_study & 32);
+        for (size_t i = 0; i < n; ++i) {
+            if (g_study & 512) { const float h = study_f16(k[i]); ks[i] = h + study_e5m2(k[i] - h); }
+            else ks[i] = study_round(k[i], g_study & 1, g_study & 8, g_study & 32);
+        }
         k = ks;
     }
     if (g_study & (2 | 16 | 64 | 256)) {

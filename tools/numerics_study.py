@@ -23,7 +23,8 @@ cfg = O.make_config(vocab_size=a.vocab, hidden_size=1024, head_dim=128, num_hidd
 VARIANTS = [("K f16", 1), ("V f16", 2), ("P f16", 4), ("K+V+P f16 (shipped round 2)", 7), ("K bf16", 8), ("V bf16", 16),
             ("K f16x2", 32), ("K f16x2 + V f16 + P f16", 32 | 2 | 4), ("K f16 + V f16 + P bf16x2", 1 | 2 | 128),
             ("K f16x2 + V f16 + P bf16x2", 32 | 2 | 128), ("K f16 + V f16x2 + P bf16x2", 1 | 64 | 128),
-            ("V f16 + e5m2 lo", 256), ("K f16 + V f16+e5m2 + P f16", 1 | 256 | 4)]
+            ("V f16 + e5m2 lo", 256), ("K f16 + V f16+e5m2 + P f16", 1 | 256 | 4),
+            ("K f16 + e5m2 lo", 512), ("K, V f16+e5m2 + P f16 hi+lo (shipped 24-bit K+V)", 512 | 256)]
 for seed in range(a.seeds):
     m = O.Model(cfg).fill_synthetic(seed, a.profile)
     ids = np.random.default_rng(100 + seed).integers(0, a.vocab, (1, a.tokens))
