@@ -103,6 +103,8 @@ if random_n:
         opts = {}
         if kw["head_dim"] == 128 and rng.random() < 0.3:
             opts["kv_v_bits"] = 24
+            if rng.random() < 0.5:
+                opts["kv_k_bits"] = 24
         if rng.random() < 0.25:
             opts["tile_min_wgs"] = 1
         cases.append((f"random {kw} {opts}", T(**kw), 64, int(rng.choice([6, 20, 28])), int(rng.choice([16, 48, 128, 512])),
