@@ -79,6 +79,7 @@ cases = [
     # (_tol 2e-3: the bound tests/test_stress_gpu.py holds the heavy profile to with the default cache; on these two-layer,
     # small-vocabulary models single rows reach 1.1e-3 even with 24-bit V -- K's f16 rounding, tools/numerics_study.py)
     ("full Qwen3-0.6B (28 layers, vocabulary 151936)", pkg.Qwen3Config.qwen3_0_6b(), 64, 28, 256, 6, short + [100, 255, 257], {}),
+    ("soak: tiny, 1500 calls on one pool (state that must survive: slots, blocks, pending ring, resident batch)", T(), 48, 12, 96, 3, None, {}),
     ("0.6B layer shapes x 2, no fused path", T(hidden_size=1024, head_dim=128, num_attention_heads=16, num_key_value_heads=8,
                                               intermediate_size=3072, vocab_size=2048), 64, 28, 128, 6, short + [255, 257], {"no_fused": 1}),
 ]
@@ -172,7 +173,7 @@ for name, cfg, NB, MS, mbt, max_new, menu, opts in cases:
         continue
     for seed in (range(first_seed, first_seed + 1) if random_n else range(100, 100 + n_seeds)):
         t0 = time.time()
-        iters = 60 if "8B" in name else 50 if "32B" in name else 50 if "full Qwen3" in name else (50 if "long" in name else (60 if random_n else 120))
+        iters = 60 if "8B" in name else 50 if "32B" in name else 50 if "full Qwen3" in name else 1500 if "soak" in name else (50 if "long" in name else (60 if random_n else 120))
         om = CachedOracle(oracle.Model(oracle_config(oracle, cfg)).fill_synthetic(seed, opts.get("_profile", 0)))
         res, errs = [None] * tp, []
         lock = threading.Lock()
