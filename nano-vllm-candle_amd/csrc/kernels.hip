@@ -1596,12 +1596,20 @@ __device__ uint4 g_attn_dummy_tile[1024];
 
 // VLO: 24-bit V (KvLayout::vlo): every V fragment comes with 8 residual bytes per lane (a 512-byte wave-load); shifted into
 // the high byte they ARE the residuals' f16 bit patterns, which a second P.V MFMA adds (the kernel is HBM-bound: V bytes x1.5)
+// gfx950, hipcc of ROCm 7.2: a v_mfma_f32_16x16x32_bf8_bf8 that takes as SrcC the result of a v_mfma_f32_16x16x32_f16 issued
+// a few instructions earlier read garbage -- the compiler leaves too few wait states between the two MFMA types and the
+// hardware does not interlock.  Seen only once the register allocator had no slack (two waves per SIMD, 230-246 registers):
+// in roomier builds the scheduler happened to put other fragments' MFMAs in between, which is luck, not a guarantee.  The
+// data dependency pins this statement between producer and consumer; 20 wait states cover a 16-pass producer.
+__device__ __forceinline__ void mfma_result_settled(f32x4& acc) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc)); }
+
 // VLO: 0 = 16-bit cache, 1 = 24-bit V, 2 = 24-bit K and V (KvLayout::klo too: four more 1 KiB wave-loads per tile, one bf8 MFMA
 // per QK^T fragment against q in bf8)
 template <int HD, int QT, int NWV, bool FUSED, int VLO = 0>
-__global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1) attn_paged_kernel(AttnArgs a) {
+__global__ void __launch_bounds__(NWV * 64, QT == 1 ? 2 : 1) attn_paged_kernel(AttnArgs a) {
     constexpr int DC = HD / 32, DT = HD / 16, DL = VLO ? DT / 2 : 1;  // DL: 1 KiB residual fragments per tile (two PV fragments each)
     constexpr bool KLO = VLO == 2;
+    constexpr bool ONE_SET = VLO != 0 && QT == 1;  // decode with a 24-bit cache: one tile set in flight per wave (see the loop)
     constexpr int RL = DL + (KLO ? DC : 0);  // residual registers per tile: V's DL, then K's [token half][DC / 2]
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* ml = reinterpret_cast<float*>(smem_raw);                          // [NWV][QT][2][16]
@@ -1904,8 +1912,12 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1
                     const uint4 pa = vl[DL + (c >> 1)], pb = vl[DL + DC / 2 + (c >> 1)];
                     const unsigned long long la = (c & 1) ? ((unsigned long long)pa.w << 32) | pa.z : ((unsigned long long)pa.y << 32) | pa.x;
                     const unsigned long long lb = (c & 1) ? ((unsigned long long)pb.w << 32) | pb.z : ((unsigned long long)pb.y << 32) | pb.x;
+                    mfma_result_settled(sa);
+                    mfma_result_settled(sb);
                     sa = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8((long)la, q8[t][c], sa, 0, 0, 0);
                     sb = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8((long)lb, q8[t][c], sb, 0, 0, 0);
+                    mfma_result_settled(sa);  // ... and the next chunk's f16 MFMAs read these as SrcC
+                    mfma_result_settled(sb);
                 }
             }
             float mt = -1e30f;
@@ -1957,6 +1969,7 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1
                 if constexpr (VLO) {
                     const uint4 pr = vl[d >> 1];
                     const unsigned long long lo8 = (d & 1) ? ((unsigned long long)pr.w << 32) | pr.z : ((unsigned long long)pr.y << 32) | pr.x;
+                    mfma_result_settled(acc);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8((long)lo8, P8, acc, 0, 0, 0);
                 }
                 o[t][d] = acc;
@@ -1980,10 +1993,10 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1
                 } else if (wave == 0) {
                     load_tile_or_dummy(kt, t_end, kaA, kbA, vfA, vlA);  // wave 0 skipped the early prefetch
                 }
-                load_tile_or_dummy(kt + NWV, t_end, kaB, kbB, vfB, vlB);
+                if constexpr (!ONE_SET) load_tile_or_dummy(kt + NWV, t_end, kaB, kbB, vfB, vlB);
             } else {
                 load_tile(min(kt, t_end - 1), kaA, kbA, vfA, vlA);
-                load_tile(min(kt + NWV, t_end - 1), kaB, kbB, vfB, vlB);
+                if constexpr (!ONE_SET) load_tile(min(kt + NWV, t_end - 1), kaB, kbB, vfB, vlB);
             }
             // refills past the end: the shared dummy tile (fused kernel: the one the model runs); the plain-q variant
             // (fine-seam op, tuning bench) keeps the clamped re-read -- the extra address selects would spill it
@@ -1991,14 +2004,24 @@ __global__ void __launch_bounds__(NWV * 64, (QT == 1 && !(VLO && FUSED)) ? 2 : 1
                 if constexpr (FUSED) load_tile_or_dummy(kt_next, t_end, ka, kb2, vf, vl);
                 else load_tile(min(kt_next, t_end - 1), ka, kb2, vf, vl);
             };
-            while (kt < t_end) {
-                compute_tile(kt, kaA, kbA, vfA, vlA);
-                refill(kt + 2 * NWV, kaA, kbA, vfA, vlA);
-                kt += NWV;
-                if (kt >= t_end) break;
-                compute_tile(kt, kaB, kbB, vfB, vlB);
-                refill(kt + 2 * NWV, kaB, kbB, vfB, vlB);
-                kt += NWV;
+            if constexpr (ONE_SET) {
+                // 24-bit cache: one 24 KiB set per wave and two waves per SIMD (a second set needs > 256 registers: half the
+                // workgroups resident, two rounds) -- the other seven waves of the CU cover this wave's round trip
+                while (kt < t_end) {
+                    compute_tile(kt, kaA, kbA, vfA, vlA);
+                    refill(kt + NWV, kaA, kbA, vfA, vlA);
+                    kt += NWV;
+                }
+            } else {
+                while (kt < t_end) {
+                    compute_tile(kt, kaA, kbA, vfA, vlA);
+                    refill(kt + 2 * NWV, kaA, kbA, vfA, vlA);
+                    kt += NWV;
+                    if (kt >= t_end) break;
+                    compute_tile(kt, kaB, kbB, vfB, vlB);
+                    refill(kt + 2 * NWV, kaB, kbB, vfB, vlB);
+                    kt += NWV;
+                }
             }
         } else {
             uint4 ka[DC], kb2[DC], vf[DT];

@@ -91,6 +91,8 @@ def test_hot_kernels_keep_their_register_budget():
     want = {  # mangled-name prefix -> minimum waves per SIMD
         "_ZN5nvllm17attn_paged_kernelILi128ELi1ELi4ELb1ELi0EEE": 2,   # fused decode attention, head_dim 128
         "_ZN5nvllm17attn_paged_kernelILi128ELi1ELi4ELb0ELi0EEE": 2,
+        "_ZN5nvllm17attn_paged_kernelILi128ELi1ELi4ELb1ELi1EEE": 2,   # ... with the 24-bit V cache (one tile set per wave)
+        "_ZN5nvllm17attn_paged_kernelILi128ELi1ELi4ELb1ELi2EEE": 2,   # ... with 24-bit K and V
         "_ZN5nvllm18gemm_rowdir_kernelILi4ELi16ELi2ELi2EEE": 4,   # QKV        (0.6B: N 4096, K 1024)
         "_ZN5nvllm18gemm_rowdir_kernelILi1ELi16ELi4ELi0EEE": 4,   # o_proj     (N 1024, K 2048)
         "_ZN5nvllm18gemm_rowdir_kernelILi6ELi16ELi2ELi1EEE": 4,   # gate/up    (N 6144, K 1024)
