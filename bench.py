@@ -551,13 +551,17 @@ def main():
         roof["achieved"] = dom_bytes / (launch_us * 1e-6) / 1e9
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
         roof["bytes_per_launch"] = dom_bytes
+    opts = dict(o.partition("=")[::2] for o in a.option)
+    kv_desc = {("16", "16"): "f16", ("16", "24"): "f16 K / 24-bit V (f16 + bf8 residual)", ("24", "24"): "24-bit K and V (f16 + bf8 residual)"}.get(
+        (opts.get("kv_k_bits", "16"), opts.get("kv_v_bits", "16")), "f16")
     out = {
         "metric": "decode tokens/sec", "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong" if use_tp else "weak", "vs_baseline": None,
-        "dtype": "bf16 weights, f16 KV cache, bf16x2(hi+lo)/f16 MFMA operands, f32 accumulate",
+        "dtype": f"bf16 weights, {kv_desc} KV cache, bf16x2(hi+lo)/f16 MFMA operands, f32 accumulate",
         "data": "synthetic",
         "config": {"workload": f"{a.model} decode, {a.batch} live sequences, prompts U[{a.prompt_min},{a.prompt_max}] seed {a.seed}",
+                   **({"options": list(a.option)} if a.option else {}),
                    "batch": a.batch, "global_batch": a.batch * replicas, "mean_context": round(mean_ctx, 1),
                    "parallelism": f"tp{world}" if use_tp else (f"dp{world} x tp1 (independent replicas, no collective)" if world > 1 else "tp1")},
         "roofline": roof,
