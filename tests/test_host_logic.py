@@ -196,3 +196,16 @@ def test_sampler_mirror_draws_from_the_softmax():
         counts = np.bincount([sample_token_host(logits, temp, sample_key(7, 11, i)) for i in range(n)], minlength=8)
         # every class within 4 standard deviations of its binomial expectation
         assert (np.abs(counts - n * p) <= 4 * np.sqrt(n * p * (1 - p)) + 1).all(), (temp, counts, n * p)
+
+
+def test_every_tool_script_compiles():
+    # tools/ run on the GPU box only; a syntax error there would surface in the middle of a measurement session
+    import ast
+    import glob
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")])
+    assert len(files) > 15
+    for f in files:
+        ast.parse(open(f).read(), filename=f)
