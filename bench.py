@@ -514,7 +514,9 @@ def main():
     if dom == "attn":
         # algorithmic bytes of one launch = every attended token's K and V of this layer, read once
         dom_bytes = float(np.mean(attn_ctx)) * kv_layer
-        dom_name = "attn_paged_kernel<128, 1, 4, true, false>"
+        _o = dict(o.partition("=")[::2] for o in a.option)  # the cache-width options select the kernel instantiation
+        _vlo = 2 if _o.get("kv_k_bits") == "24" else (1 if _o.get("kv_v_bits") == "24" else 0)
+        dom_name = f"attn_paged_kernel<128, 1, 4, true, {_vlo}>"
     elif dom == "lm_head":
         dom_bytes = float(lm_bytes)
         dom_name = "lmhead_kernel"

@@ -59,14 +59,14 @@ if ks and prof_bench:
     info = prof_bench["all_decode_steps"]
     wb = info["weight_bytes"]
     # which projection a register-direct instantiation is, by its template arguments <NT, 16, TK, EPI> (Qwen3-0.6B shapes)
-    alg = {"attn_paged_kernel<128, 1, 4, true, false>": info["attn_algorithmic_bytes_per_launch"],
+    alg = {"attn_paged_kernel<128, 1, 4, true, 0>": info["attn_algorithmic_bytes_per_launch"],
            "gemm_rowdir_kernel<4, 16, 2, 2>": wb["qkv"], "gemm_rowdir_kernel<1, 16, 4, 0>": wb["o_proj"],
            "gemm_rowdir_kernel<6, 16, 2, 1>": wb["gate_up"], "gemm_rowdir_kernel<1, 16, 6, 0>": wb["down"],
            "lmhead_kernel<4, 5, 4>": wb["lm_head"]}
     fetch = fetch_per_kernel(pmc) if pmc else {}
     pmc_alg = dict(alg)
     if pmc_bench:
-        pmc_alg["attn_paged_kernel<128, 1, 4, true, false>"] = pmc_bench["all_decode_steps"]["attn_algorithmic_bytes_per_launch"]
+        pmc_alg["attn_paged_kernel<128, 1, 4, true, 0>"] = pmc_bench["all_decode_steps"]["attn_algorithmic_bytes_per_launch"]
     rows = []
     with open(ks) as f:
         for row in csv.DictReader(f):
@@ -86,7 +86,7 @@ if ks and prof_bench:
         step_us = sum(r[2] * r[1] for r in rows) / info["steps"]
         g.write(f"# sum of these kernels per decode step: {step_us:.1f} us; bench ms_per_step of the same run: {prof_bench['ms_per_step']:.4f}\n")
     print("wrote", dst)
-    dom = "attn_paged_kernel<128, 1, 4, true, false>"
+    dom = "attn_paged_kernel<128, 1, 4, true, 0>"
     if dom in fetch and pmc_bench:
         js = {"_comment": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --skip-tp-leg "
                           "(the driver's command) on MI355X; FETCH_SIZE KB x 2 (gfx950 wide-stream correction, MI355X_MICROARCH.md HBM section) x 1024; algorithmic = mean over "
