@@ -72,7 +72,8 @@ def random_calls(m, om, cfg, seed, iters, NB, MS, lock=None, max_new=2, lens_men
 
     ops = 0
     for it in range(iters):
-        op = rng.choice(["add", "decode", "resident", "pipelined", "grow", "reprefill", "free"], p=[0.22, 0.28, 0.12, 0.08, 0.1, 0.08, 0.12])
+        op = rng.choice(["add", "decode", "resident", "pipelined", "grow", "reprefill", "free", "sample"],
+                        p=[0.22, 0.24, 0.11, 0.07, 0.09, 0.07, 0.12, 0.08])
         cur_op[0] = f"call {it} {op}"
         if op == "add" or not live:
             n_new = int(rng.integers(1, max_new + 1))
@@ -103,6 +104,26 @@ def random_calls(m, om, cfg, seed, iters, NB, MS, lock=None, max_new=2, lens_men
                 continue
             got, lg = m.step(ids, [live[s] for s in ids], False, want_logits=True)
             check(ids, got, lg)
+        elif op == "sample":
+            # sample_token on the device (llm_engine.rs:97-133) over a shuffled subset: logits against the oracle, the drawn ids
+            # against the host mirror of the draw applied to the GPU's own logits (engine.py: sample_token_host)
+            from nano_vllm_candle_amd.engine import sample_key, sample_token_host
+
+            ids = [int(s) for s in rng.permutation(list(live))[: int(rng.integers(1, len(live) + 1))]]
+            if m.free_blocks() < len(ids):
+                continue
+            temps = [float(t) for t in rng.choice([0.0, 0.5, 1.0, 2.0], len(ids))]
+            sseed = int(rng.integers(0, 2**62))
+            got, lg = m.step_sample(ids, [live[s] for s in ids], False, temps, sseed, want_logits=True)
+            with guard:
+                _, rlgs = om.run_greedy([live[sid] for sid in ids])
+            for k, sid in enumerate(ids):
+                e = row_rel_err(lg[k:k + 1], rlgs[k:k + 1])
+                worst = max(worst, e)
+                assert e < tol, (cur_op[0], len(ids), sid, len(live[sid]), e)
+                want = sample_token_host(lg[k], temps[k], sample_key(sseed, sid, len(live[sid])))
+                assert int(got[k]) == int(want), (cur_op[0], len(ids), sid, temps[k], int(got[k]), int(want))
+                live[sid].append(int(got[k]))
         elif op in ("resident", "pipelined"):
             ids = [int(s) for s in rng.permutation(list(live))[: int(rng.integers(1, len(live) + 1))]]
             k = int(rng.integers(1, 4))
